@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI in include/dualdiff_hip.h.
+
+The library is the product: there is no CPU / eager fallback.  If it cannot be loaded the
+import of any op fails loudly (RuntimeError) instead of silently running something else.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p)
+
+from . import _build
+
+DD_F16, DD_BF16 = 0, 1
+DD_EPI_NONE, DD_EPI_GEGLU, DD_EPI_SILU = 0, 1, 2
+
+
+class GemmDesc(Structure):
+    _fields_ = [
+        ("a", c_void_p), ("a2", c_void_p), ("lda", c_int64), ("lda2", c_int64), ("k1", c_int32),
+        ("rows", c_int32), ("n", c_int32), ("k", c_int32),
+        ("w", c_void_p), ("bias", c_void_p), ("rowvec", c_void_p),
+        ("rows_per_inst", c_int32), ("ld_rowvec", c_int32),
+        ("res", c_void_p), ("ldres", c_int64),
+        ("out", c_void_p), ("ldc", c_int64),
+        ("alpha", c_float), ("accumulate", c_int32), ("epilogue", c_int32),
+        ("conv", c_int32), ("hin", c_int32), ("win", c_int32), ("cin", c_int32),
+        ("hv", c_int32), ("wv", c_int32), ("hout", c_int32), ("wout", c_int32), ("stride", c_int32),
+        ("dtype", c_int32), ("tile", c_int32), ("split_k", c_int32),
+        ("ws", c_void_p), ("ws_bytes", c_int64),
+    ]
+
+
+class AttnDesc(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
+        ("ldq", c_int64), ("ldk", c_int64), ("ldv", c_int64), ("ldo", c_int64),
+        ("q_batch_stride", c_int64), ("k_batch_stride", c_int64),
+        ("v_batch_stride", c_int64), ("o_batch_stride", c_int64),
+        ("batch", c_int32), ("heads", c_int32), ("head_dim", c_int32), ("lq", c_int32), ("lk", c_int32),
+        ("scale", c_float),
+        ("kv_batch_map", c_void_p),
+        ("accumulate", c_int32), ("dtype", c_int32), ("variant", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "dd_abi_version": (c_int32, []),
+    "dd_error_string": (c_char_p, [c_int32]),
+    "dd_target_arch": (c_char_p, []),
+    "dd_gemm": (c_int32, [POINTER(GemmDesc), c_void_p]),
+    "dd_gemm_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
+    "dd_gemm_num_tiles": (c_int32, []),
+    "dd_gemm_kernel_name": (c_char_p, [POINTER(GemmDesc)]),
+    "dd_groupnorm_nhwc": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                    c_int32, c_int32, c_int32, c_float, c_int32, c_int32,
+                                    c_void_p, c_int64, c_void_p]),
+    "dd_groupnorm_workspace_bytes": (c_int64, [c_int32, c_int32]),
+    "dd_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
+                               c_int32, c_void_p]),
+    "dd_attention": (c_int32, [POINTER(AttnDesc), c_void_p]),
+    "dd_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "dd_scale": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p]),
+    "dd_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "dd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dd_timestep_embedding": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
+                                        c_int32, c_void_p]),
+    "dd_conv3x3_small_cout": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                        c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dd_cfg_ddim_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_int64, c_int32, c_void_p]),
+}
+
+_LIB = None
+
+
+def lib_path():
+    return _build.lib_path()
+
+
+def load(build_if_missing=True):
+    """Load libdualdiff_hip.so (building it with hipcc when absent and a compiler exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError("dualdiff_amd: %s is missing (run __graft_entry__.build())" % path)
+        _build.build_native()
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # fail loudly: there is no fallback path
+        raise RuntimeError("dualdiff_amd: cannot load HIP library %s: %s" % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RuntimeError("dualdiff_amd: %s does not export %s" % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dd_abi_version() != 1:
+        raise RuntimeError("dualdiff_amd: ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dd_error_string(rc).decode()
+        raise RuntimeError("dualdiff_amd.%s failed: %s (%d)" % (what, msg, rc))

@@ -1,0 +1,309 @@
+// Flash-style scaled-dot-product attention for gfx950 (head_dim 40 / 80 / 160, no mask).
+//
+// Structure (per workgroup = 4 waves, each wave owns QT*16 query rows; K/V tiles of 64 keys
+// are staged once per workgroup in LDS and shared by the 4 waves):
+//  * "swapped" products so that the softmax row lives on a lane:
+//        S^T[key][q] = K . Q^T     (MFMA A = K rows, B = Q rows; both d-contiguous)
+//        O^T[d][q]   = V^T . P^T   (MFMA A = V^T via ds_read_b64_tr_b16, B = P^T)
+//    The S^T accumulator of a lane is 8 scores of ONE query row per 32-key chunk, and it is
+//    already laid out as the B operand of the second product (the k index of both operands
+//    is permuted identically) — no LDS round trip and no cross-lane movement for P.
+//  * online softmax in fp32 (exp2 with the scale folded into log2e), row max reduced with two
+//    xor-shuffles (lane groups 16/32 apart hold the other keys of the same query row).
+//  * head_dim is padded with zeros in LDS to a multiple of 32 for QK^T (40->64, 80->96) and
+//    to a multiple of 16 for PV (40->48); rows are padded by 16 B against bank conflicts.
+//  * register-staged prefetch of the next K/V tile while the current one is consumed.
+//  * kv_batch_map + accumulate implement the neighbour-view attention (attn4) as two calls
+//    that read the neighbours' K/V in place and sum the normalised outputs.
+#include "dd_common.h"
+
+namespace {
+
+struct AttnParams {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t qbs, kbs, vbs, obs;
+  int batch, heads, lq, lk;
+  float scale_log2;
+  const int32_t* kv_map;
+  int accumulate;
+};
+
+constexpr int KV_TILE = 64;
+
+template <typename T, int D, int QT, bool TR>
+__global__ __launch_bounds__(256)
+void dd_attn_kernel(const AttnParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  using V4 = typename dd_vec<T>::v4;
+  constexpr int DQ = (D + 31) / 32 * 32;       // padded head dim for QK^T
+  constexpr int KSTEPS = DQ / 32;
+  constexpr int DVT = (D + 15) / 16;           // 16-wide d tiles for PV
+  constexpr int KSTR = DQ + 8;                 // LDS row strides (elements)
+  constexpr int VSTR = DVT * 16 + 8;
+  constexpr int KCH = DQ / 8;                  // 16-B chunks per K row in LDS
+  constexpr int VCH = DVT * 2;                 // 16-B chunks per V row in LDS
+  constexpr int DCH = D / 8;                   // valid chunks per global row
+  constexpr int K_PER_THR = (KV_TILE * KCH + 255) / 256;
+  constexpr int V_PER_THR = (KV_TILE * VCH + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + KV_TILE * KSTR;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int g = lane >> 4;        // lane group 0..3
+  const int c = lane & 15;
+
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads;
+  const int h = bh - b * p.heads;
+  const int kb = p.kv_map ? p.kv_map[b] : b;
+  const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
+
+  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * D;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * D;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * D;
+
+  // ---- Q fragments (B operand of S^T = K Q^T), kept in registers -----------------------
+  V8 qf[QT][KSTEPS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + c;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < p.lq && d0 < D) v = dd_ld16(qbase + (int64_t)qrow * p.ldq + d0);
+      qf[qt][ks] = dd_as_v8<T>(v);
+    }
+  }
+
+  f32x4 oacc[DVT][QT];
+#pragma unroll
+  for (int i = 0; i < DVT; ++i)
+#pragma unroll
+    for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) { m_run[j] = -1e30f; l_run[j] = 0.f; }
+
+  u32x4 kreg[K_PER_THR], vreg[V_PER_THR];
+
+  auto load_kv = [&](int tile0) {
+#pragma unroll
+    for (int i = 0; i < K_PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / KCH, ch = idx - row * KCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < KV_TILE * KCH && ch < DCH && tile0 + row < p.lk)
+        v = dd_ld16(kbase + (int64_t)(tile0 + row) * p.ldk + ch * 8);
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < V_PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / VCH, ch = idx - row * VCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < KV_TILE * VCH && ch < DCH && tile0 + row < p.lk)
+        v = dd_ld16(vbase + (int64_t)(tile0 + row) * p.ldv + ch * 8);
+      vreg[i] = v;
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < K_PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / KCH, ch = idx - row * KCH;
+      if (idx < KV_TILE * KCH) dd_st16(Ks + row * KSTR + ch * 8, kreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < V_PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / VCH, ch = idx - row * VCH;
+      if (idx < KV_TILE * VCH) dd_st16(Vs + row * VSTR + ch * 8, vreg[i]);
+    }
+  };
+
+  const int ntiles = (p.lk + KV_TILE - 1) / KV_TILE;
+  load_kv(0);
+
+  for (int it = 0; it < ntiles; ++it) {
+    const int tile0 = it * KV_TILE;
+    __syncthreads();            // previous tile fully consumed by every wave
+    store_kv();
+    __syncthreads();            // tile visible
+    if (it + 1 < ntiles) load_kv(tile0 + KV_TILE);   // prefetch under the MFMAs below
+
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int key0 = tile0 + cc * 32;
+      if (key0 >= p.lk) break;                        // uniform
+      // ---- S^T = K Q^T for 32 keys ------------------------------------------------------
+      f32x4 sacc[2][QT];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) sacc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        V8 kf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          kf[t] = dd_as_v8<T>(dd_ld16(Ks + (cc * 32 + t * 16 + c) * KSTR + ks * 32 + g * 8));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < QT; ++j) sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], sacc[t][j]);
+      }
+      // ---- online softmax; lane holds keys key0 + t*16 + g*4 + r for query column c -------
+      const bool tail = key0 + 32 > p.lk;             // uniform
+      V8 pf[QT];
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        float s[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = sacc[t][j][r] * p.scale_log2;
+            if (tail && key0 + t * 16 + g * 4 + r >= p.lk) v = -INFINITY;
+            s[t * 4 + r] = v;
+          }
+        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
+                         fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[j], mx);
+        const float alpha = exp2f(m_run[j] - m_new);
+        m_run[j] = m_new;
+        float ls = 0.f;
+        V8 pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pe = exp2f(s[e] - m_new);
+          ls += pe;
+          pv[e] = (T)pe;
+        }
+        pf[j] = pv;
+        l_run[j] = l_run[j] * alpha + ls;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+          oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
+          oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
+        }
+      }
+      // ---- O^T += V^T P^T -----------------------------------------------------------------
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt) {
+        V8 vf;
+        if constexpr (TR) {
+          // hardware transpose read: 16-lane group g reads a 4-key x 16-d block; lane 4q+pp
+          // supplies the address of key row q, columns 4pp..4pp+3, and receives column (lane&15).
+          const T* a0 = Vs + (cc * 32 + g * 4 + (c >> 2)) * VSTR + dt * 16 + (c & 3) * 4;
+          const T* a1 = a0 + 16 * VSTR;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(a0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(a1));
+          __builtin_memcpy(&vf, &lo, 8);
+          __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            vf[e] = Vs[(cc * 32 + (e >> 2) * 16 + g * 4 + (e & 3)) * VSTR + dt * 16 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < QT; ++j) oacc[dt][j] = dd_mfma16(vf, pf[j], oacc[dt][j]);
+      }
+    }
+  }
+
+  // ---- finalise: O[q][d] = O^T / l ------------------------------------------------------
+  T* obase = reinterpret_cast<T*>(p.o) + (int64_t)b * p.obs + h * D;
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    float l = l_run[j];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int qrow = q0 + j * 16 + c;
+    if (qrow >= p.lq) continue;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      const int d0 = dt * 16 + g * 4;
+      if (d0 >= D) continue;
+      T* dst = obase + (int64_t)qrow * p.ldo + d0;
+      float o4[4] = {oacc[dt][j][0] * inv, oacc[dt][j][1] * inv,
+                     oacc[dt][j][2] * inv, oacc[dt][j][3] * inv};
+      if (p.accumulate) {
+        V4 prev = *reinterpret_cast<const V4*>(dst);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] += (float)prev[e];
+      }
+      V4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (T)o4[e];
+      *reinterpret_cast<V4*>(dst) = ov;
+    }
+  }
+}
+
+template <typename T, int D, int QT, bool TR>
+int launch_attn(const AttnParams& p, hipStream_t s) {
+  constexpr int DQ = (D + 31) / 32 * 32;
+  constexpr int DVT = (D + 15) / 16;
+  constexpr size_t smem = (size_t)KV_TILE * ((DQ + 8) + (DVT * 16 + 8)) * sizeof(T);
+  const int qblk = 4 * QT * 16;
+  dim3 grid((p.lq + qblk - 1) / qblk, p.batch * p.heads);
+  hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR>), grid, dim3(256), smem, s, p);
+  return dd_check_launch();
+}
+
+template <typename T, int D>
+int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
+  // 32 query rows per wave when the sequence is long enough to fill the chip, else 16
+  const long blocks128 = (long)((p.lq + 127) / 128) * p.batch * p.heads;
+  const bool qt2 = p.lq >= 256 && blocks128 >= 512;
+  if (variant == 1) {
+    return qt2 ? launch_attn<T, D, 2, false>(p, s) : launch_attn<T, D, 1, false>(p, s);
+  }
+  return qt2 ? launch_attn<T, D, 2, true>(p, s) : launch_attn<T, D, 1, true>(p, s);
+}
+
+template <typename T>
+int launch_attn_t(const dd_attn_desc* d, const AttnParams& p, hipStream_t s) {
+  switch (d->head_dim) {
+    case 40: return launch_attn_d<T, 40>(p, d->variant, s);
+    case 80: return launch_attn_d<T, 80>(p, d->variant, s);
+    case 160: return launch_attn_d<T, 160>(p, d->variant, s);
+  }
+  return DD_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
+  if (!d || !d->q || !d->k || !d->v || !d->o) return DD_ERR_BAD_ARG;
+  if (d->batch <= 0 || d->heads <= 0 || d->lq <= 0 || d->lk <= 0) return DD_ERR_BAD_ARG;
+  if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7)) return DD_ERR_BAD_ARG;
+  if ((d->q_batch_stride & 7) || (d->k_batch_stride & 7) || (d->v_batch_stride & 7) ||
+      (d->o_batch_stride & 7)) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(d->q) || !dd_aligned16(d->k) || !dd_aligned16(d->v) || !dd_aligned16(d->o))
+    return DD_ERR_BAD_ARG;
+  if (d->head_dim != 40 && d->head_dim != 80 && d->head_dim != 160) return DD_ERR_UNSUPPORTED;
+  if ((long)d->batch * d->heads > 65535) return DD_ERR_UNSUPPORTED;
+  AttnParams p{};
+  p.q = d->q; p.k = d->k; p.v = d->v; p.o = d->o;
+  p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
+  p.qbs = d->q_batch_stride; p.kbs = d->k_batch_stride; p.vbs = d->v_batch_stride; p.obs = d->o_batch_stride;
+  p.batch = d->batch; p.heads = d->heads; p.lq = d->lq; p.lk = d->lk;
+  p.scale_log2 = d->scale * 1.44269504088896340736f;
+  p.kv_map = d->kv_batch_map; p.accumulate = d->accumulate;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == DD_F16) return launch_attn_t<_Float16>(d, p, s);
+  return launch_attn_t<__bf16>(d, p, s);
+}

@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dualdiff_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define DD_WAVE 64
+
+template <typename T> struct dd_vec;
+template <> struct dd_vec<_Float16> { using v8 = f16x8; using v4 = f16x4; };
+template <> struct dd_vec<__bf16>   { using v8 = bf16x8; using v4 = bf16x4; };
+
+__device__ __forceinline__ f32x4 dd_mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 dd_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// 16-byte vector <-> 8 x T
+template <typename T>
+__device__ __forceinline__ typename dd_vec<T>::v8 dd_as_v8(u32x4 u) {
+  typename dd_vec<T>::v8 r;
+  __builtin_memcpy(&r, &u, 16);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ u32x4 dd_as_u4(typename dd_vec<T>::v8 v) {
+  u32x4 r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
+}
+
+__device__ __forceinline__ u32x4 dd_ld16(const void* p) {
+  return *reinterpret_cast<const u32x4*>(p);
+}
+__device__ __forceinline__ void dd_st16(void* p, u32x4 v) {
+  *reinterpret_cast<u32x4*>(p) = v;
+}
+
+template <typename T>
+__device__ __forceinline__ void dd_unpack8(u32x4 u, float (&f)[8]) {
+  typename dd_vec<T>::v8 v = dd_as_v8<T>(u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T>
+__device__ __forceinline__ u32x4 dd_pack8(const float (&f)[8]) {
+  typename dd_vec<T>::v8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (T)f[i];
+  return dd_as_u4<T>(v);
+}
+
+__device__ __forceinline__ float dd_silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dd_gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float dd_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float dd_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int dd_check_launch() {
+  return hipGetLastError() == hipSuccess ? DD_OK : DD_ERR_LAUNCH;
+}
+static inline bool dd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,298 @@
+// Small HBM-bound kernels of the denoising step: residual adds, layout converts at the
+// 4-channel latent boundary, sinusoidal timestep embedding, conv_out (320->4) and the fused
+// CFG + DDIM update.  All vectorised to 16 B per lane where the shape allows.
+#include "dd_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_add_kernel(const T* a, const T* b, const T* c, T* y, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    dd_unpack8<T>(dd_ld16(a + i * 8), fa);
+    dd_unpack8<T>(dd_ld16(b + i * 8), fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+    if (c) {
+      dd_unpack8<T>(dd_ld16(c + i * 8), fb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+    }
+    dd_st16(y + i * 8, dd_pack8<T>(fa));
+  }
+}
+
+template <typename T, int OP>   // OP 0: scale, 1: silu
+__global__ __launch_bounds__(256)
+void dd_unary_kernel(const T* x, T* y, float s, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float f[8];
+    dd_unpack8<T>(dd_ld16(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = OP == 0 ? f[e] * s : dd_silu_f(f[e]);
+    dd_st16(y + i * 8, dd_pack8<T>(f));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_nchw_to_nhwc_kernel(const T* x, T* y, int m, int c, int hw, int c_pad) {
+  const int64_t total = (int64_t)m * hw * c_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c_pad);
+    const int64_t row = i / c_pad;
+    const int px = (int)(row % hw);
+    const int inst = (int)(row / hw);
+    y[i] = ch < c ? x[((int64_t)inst * c + ch) * hw + px] : (T)0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_nhwc_to_nchw_kernel(const T* x, T* y, int m, int c, int hw, int ldx) {
+  const int64_t total = (int64_t)m * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const int64_t r = i / hw;
+    const int ch = (int)(r % c);
+    const int inst = (int)(r / c);
+    y[i] = x[((int64_t)inst * hw + px) * ldx + ch];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_timestep_embedding_kernel(const float* t, T* out, int n, int dim, int flip, float shift) {
+  const int half = dim / 2;
+  const int total = n * half;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / half, j = i - row * half;
+    const float freq = expf(-9.210340371976184f * (float)j / ((float)half - shift));
+    const float arg = t[row] * freq;
+    const float sv = sinf(arg), cv = cosf(arg);
+    T* o = out + (int64_t)row * dim;
+    if (flip) { o[j] = (T)cv; o[half + j] = (T)sv; }
+    else      { o[j] = (T)sv; o[half + j] = (T)cv; }
+  }
+}
+
+// conv3x3 (pad 1, stride 1) with a handful of output channels: one wave per output pixel,
+// the 9*cin products are spread over the 64 lanes and reduced with shuffles.  Output NCHW.
+template <typename T, int MAXCO>
+__global__ __launch_bounds__(256)
+void dd_conv3x3_small_kernel(const T* x, const T* w, const T* bias, T* y,
+                             int m, int h, int wd, int cin, int cout) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t npix = (int64_t)m * h * wd;
+  if (pix >= npix) return;
+  const int hw = h * wd;
+  const int inst = (int)(pix / hw);
+  const int rem = (int)(pix - (int64_t)inst * hw);
+  const int oy = rem / wd, ox = rem - oy * wd;
+  const int cv = cin >> 3;
+  const int nvec = 9 * cv;
+  float acc[MAXCO];
+#pragma unroll
+  for (int o = 0; o < MAXCO; ++o) acc[o] = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    const int tap = v / cv, cvi = v - tap * cv;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = oy + ky - 1, ix = ox + kx - 1;
+    if (iy < 0 || iy >= h || ix < 0 || ix >= wd) continue;
+    float f[8];
+    dd_unpack8<T>(dd_ld16(x + (((int64_t)inst * h + iy) * wd + ix) * cin + cvi * 8), f);
+#pragma unroll
+    for (int o = 0; o < MAXCO; ++o) {
+      if (o < cout) {
+        float g[8];
+        dd_unpack8<T>(dd_ld16(w + (int64_t)o * 9 * cin + v * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o] += f[e] * g[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < MAXCO; ++o) {
+    const float s = dd_wave_sum(acc[o]);
+    if (lane == 0 && o < cout) {
+      const float bv = bias ? (float)bias[o] : 0.f;
+      y[((int64_t)inst * cout + o) * hw + rem] = (T)(s + bv);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_cfg_ddim_kernel(const T* eps, const T* x, T* x_out, T* x_dup, const float* coef,
+                        float guidance, int64_t n) {
+  const float sa_t = coef[0], s1a_t = coef[1], sa_p = coef[2], s1a_p = coef[3];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float eu = (float)eps[i], ec = (float)eps[n + i];
+    // reference rounds the guided noise to the model dtype before scheduler.step
+    const float e = (float)(T)(eu + guidance * (ec - eu));
+    const float xv = (float)x[i];
+    const float x0 = (xv - s1a_t * e) / sa_t;
+    const T r = (T)(sa_p * x0 + s1a_p * e);
+    x_out[i] = r;
+    if (x_dup) x_dup[i] = r;
+  }
+}
+
+inline unsigned grid_for(int64_t work, int per_block = 256, unsigned cap = 2048) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int dd_add(const void* a, const void* b, const void* c, void* y, int64_t n,
+                      int32_t dtype, dd_stream_t stream) {
+  if (!a || !b || !y || n <= 0 || (n & 7)) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(a) || !dd_aligned16(b) || !dd_aligned16(y) || (c && !dd_aligned16(c))) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nvec = n / 8;
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_add_kernel<_Float16>, dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const _Float16*)a, (const _Float16*)b, (const _Float16*)c, (_Float16*)y, nvec);
+  else
+    hipLaunchKernelGGL(dd_add_kernel<__bf16>, dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const __bf16*)a, (const __bf16*)b, (const __bf16*)c, (__bf16*)y, nvec);
+  return dd_check_launch();
+}
+
+extern "C" int dd_scale(const void* x, void* y, float sc, int64_t n, int32_t dtype, dd_stream_t stream) {
+  if (!x || !y || n <= 0 || (n & 7)) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(x) || !dd_aligned16(y)) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nvec = n / 8;
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL((dd_unary_kernel<_Float16, 0>), dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const _Float16*)x, (_Float16*)y, sc, nvec);
+  else
+    hipLaunchKernelGGL((dd_unary_kernel<__bf16, 0>), dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const __bf16*)x, (__bf16*)y, sc, nvec);
+  return dd_check_launch();
+}
+
+extern "C" int dd_silu(const void* x, void* y, int64_t n, int32_t dtype, dd_stream_t stream) {
+  if (!x || !y || n <= 0 || (n & 7)) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(x) || !dd_aligned16(y)) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nvec = n / 8;
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL((dd_unary_kernel<_Float16, 1>), dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const _Float16*)x, (_Float16*)y, 1.f, nvec);
+  else
+    hipLaunchKernelGGL((dd_unary_kernel<__bf16, 1>), dim3(grid_for(nvec)), dim3(256), 0, s,
+                       (const __bf16*)x, (__bf16*)y, 1.f, nvec);
+  return dd_check_launch();
+}
+
+extern "C" int dd_nchw_to_nhwc(const void* x, void* y, int32_t m, int32_t c, int32_t hw,
+                               int32_t c_pad, int32_t dtype, dd_stream_t stream) {
+  if (!x || !y || m <= 0 || c <= 0 || hw <= 0 || c_pad < c) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)m * hw * c_pad;
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_nchw_to_nhwc_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const _Float16*)x, (_Float16*)y, m, c, hw, c_pad);
+  else
+    hipLaunchKernelGGL(dd_nchw_to_nhwc_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const __bf16*)x, (__bf16*)y, m, c, hw, c_pad);
+  return dd_check_launch();
+}
+
+extern "C" int dd_nhwc_to_nchw(const void* x, void* y, int32_t m, int32_t c, int32_t hw,
+                               int32_t ldx, int32_t dtype, dd_stream_t stream) {
+  if (!x || !y || m <= 0 || c <= 0 || hw <= 0 || ldx < c) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)m * hw * c;
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_nhwc_to_nchw_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const _Float16*)x, (_Float16*)y, m, c, hw, ldx);
+  else
+    hipLaunchKernelGGL(dd_nhwc_to_nchw_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s,
+                       (const __bf16*)x, (__bf16*)y, m, c, hw, ldx);
+  return dd_check_launch();
+}
+
+extern "C" int dd_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
+                                     int32_t flip_sin_to_cos, float freq_shift,
+                                     int32_t dtype, dd_stream_t stream) {
+  if (!t || !out || n <= 0 || dim <= 0 || (dim & 1)) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int total = n * (dim / 2);
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_timestep_embedding_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, s,
+                       t, (_Float16*)out, n, dim, flip_sin_to_cos, freq_shift);
+  else
+    hipLaunchKernelGGL(dd_timestep_embedding_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s,
+                       t, (__bf16*)out, n, dim, flip_sin_to_cos, freq_shift);
+  return dd_check_launch();
+}
+
+extern "C" int dd_conv3x3_small_cout(const void* x, const void* w, const void* bias, void* y_nchw,
+                                     int32_t m, int32_t h, int32_t wd, int32_t cin, int32_t cout,
+                                     int32_t dtype, dd_stream_t stream) {
+  if (!x || !w || !y_nchw || m <= 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0) return DD_ERR_BAD_ARG;
+  if ((cin & 7) || cout > 8) return DD_ERR_UNSUPPORTED;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(x) || !dd_aligned16(w)) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t npix = (int64_t)m * h * wd;
+  const unsigned blocks = (unsigned)((npix + 3) / 4);
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL((dd_conv3x3_small_kernel<_Float16, 8>), dim3(blocks), dim3(256), 0, s,
+                       (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
+                       (_Float16*)y_nchw, m, h, wd, cin, cout);
+  else
+    hipLaunchKernelGGL((dd_conv3x3_small_kernel<__bf16, 8>), dim3(blocks), dim3(256), 0, s,
+                       (const __bf16*)x, (const __bf16*)w, (const __bf16*)bias,
+                       (__bf16*)y_nchw, m, h, wd, cin, cout);
+  return dd_check_launch();
+}
+
+extern "C" int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, void* x_dup,
+                                const float* coef, float guidance, int64_t n,
+                                int32_t dtype, dd_stream_t stream) {
+  if (!eps || !x || !x_out || !coef || n <= 0) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_cfg_ddim_kernel<_Float16>, dim3(grid_for(n)), dim3(256), 0, s,
+                       (const _Float16*)eps, (const _Float16*)x, (_Float16*)x_out, (_Float16*)x_dup,
+                       coef, guidance, n);
+  else
+    hipLaunchKernelGGL(dd_cfg_ddim_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, s,
+                       (const __bf16*)eps, (const __bf16*)x, (__bf16*)x_out, (__bf16*)x_dup,
+                       coef, guidance, n);
+  return dd_check_launch();
+}
+
+extern "C" int dd_abi_version(void) { return DD_ABI_VERSION; }
+extern "C" const char* dd_target_arch(void) { return "gfx950"; }
+extern "C" const char* dd_error_string(int code) {
+  switch (code) {
+    case DD_OK: return "ok";
+    case DD_ERR_BAD_ARG: return "bad argument (null / non-positive size / misaligned)";
+    case DD_ERR_UNSUPPORTED: return "unsupported shape or option";
+    case DD_ERR_LAUNCH: return "kernel launch failed";
+    case DD_ERR_WORKSPACE: return "workspace too small";
+  }
+  return "unknown error";
+}

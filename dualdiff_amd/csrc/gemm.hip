@@ -1,0 +1,553 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution with fused epilogue for gfx950.
+//
+//   out[r, n] (op)= alpha * (sum_k A[r,k] W[n,k] + bias[n] + rowvec[r/rpi, n]) + res[r, n]
+//
+// Design (MI355X-first, not a CUDA tiling):
+//  * wave64, v_mfma_f32_16x16x32_{f16,bf16}; fp32 accumulate.
+//  * The MFMA "A" operand is the WEIGHT tile and the "B" operand the ACTIVATION tile, so
+//    the accumulator of a lane is a run of consecutive output channels of one row.  The
+//    weight rows of a wave are permuted on the global->LDS load so that each lane ends up
+//    with 4*TN *consecutive* channels -> 16-byte NHWC stores, 128 B contiguous per row.
+//  * Both operands are K-contiguous ([rows][K] activations, [N][K] weights), staged as
+//    [row][64] tiles in LDS with a 16-byte-chunk XOR swizzle (conflict-free ds_read_b128).
+//  * Register-staged software pipeline: global loads of K-tile t+1 are issued before the
+//    MFMAs of tile t and written to the other LDS buffer afterwards (one barrier / K-step).
+//  * conv mode gathers the im2col row on the fly (NHWC: one tap = one contiguous Cin run);
+//    padding, stride 2 and the nearest-neighbour upsample are folded into the gather.
+//  * XCD-aware tile order: consecutive tiles that share an activation panel are mapped to
+//    the same XCD (private L2).
+//  * split-K for the deep, weight-bound levels (336..1092 rows x K up to 23040).
+#include "dd_common.h"
+
+namespace {
+
+constexpr int BK = 64;  // K elements per pipeline step (8 chunks of 16 B per tile row)
+
+struct GemmParams {
+  const void* a; const void* a2; int64_t lda, lda2; int k1;
+  int rows, n, k;
+  const void* w; const void* bias; const void* rowvec; int rows_per_inst, ld_rowvec;
+  const void* res; int64_t ldres;
+  void* out; int64_t ldc;
+  float alpha; int accumulate; int act;
+  int hin, win, cin, hv, wv, hout, wout, stride, upsample;
+  float scale_h, scale_w;
+  int k_per_split;
+  float* partial;
+  int tiles_m, tiles_n;
+};
+
+// --- epilogue on 8 consecutive output channels of one row --------------------------------
+template <typename T>
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int row, int col, float (&v)[8]) {
+  if (p.bias) {
+    float b[8];
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + col), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (p.rowvec) {
+    const int inst = row / p.rows_per_inst;
+    float b[8];
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.rowvec) + (int64_t)inst * p.ld_rowvec + col), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= p.alpha;
+  if (p.res) {
+    float b[8];
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.res) + (int64_t)row * p.ldres + col), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (p.act == DD_EPI_SILU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = dd_silu_f(v[i]);
+  }
+  T* o = reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col;
+  if (p.accumulate) {
+    float b[8];
+    dd_unpack8<T>(dd_ld16(o), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  dd_st16(o, dd_pack8<T>(v));
+}
+
+// XCD-aware bijective remap of a 1-D block id (guide T1): blocks b, b+8, ... share an XCD;
+// give each XCD a contiguous range of tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
+void dd_gemm_kernel(const GemmParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 16;
+  constexpr int BN = WAVES_N * TN * 16;           // weight-tile rows
+  constexpr int BN_OUT = GEGLU ? BN / 2 : BN;     // output columns per block
+  constexpr int XI = BM * 8 / NT;                 // 16-B chunks per thread, activation tile
+  constexpr int WI = BN * 8 / NT;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* Xs = reinterpret_cast<T*>(smem);                         // [2][BM][64]
+  T* Ws = Xs + 2 * BM * BK;                                   // [2][BN][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = tile / p.tiles_n;
+  const int tile_n = tile % p.tiles_n;
+  const int block_m0 = tile_m * BM;
+  const int block_n0 = tile_n * BN_OUT;
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.k, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // ---- per-thread loader state --------------------------------------------------------
+  const int lchunk = tid & 7;        // which 16-B chunk of the 128-B tile row
+  const int lrow0 = tid >> 3;        // first tile row handled by this thread
+  constexpr int LROW_STEP = NT / 8;
+
+  // activation rows
+  int xm[XI];          // dense: global row (or -1).  conv: instance pixel base (or -1)
+  int xiy[XI], xix[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int r = block_m0 + lrow0 + i * LROW_STEP;
+    if (r < p.rows) {
+      if (CONV) {
+        const int hw = p.hout * p.wout;
+        const int inst = r / hw;
+        const int rem = r - inst * hw;
+        const int oy = rem / p.wout;
+        const int ox = rem - oy * p.wout;
+        xm[i] = inst;
+        xiy[i] = oy * p.stride - 1;
+        xix[i] = ox * p.stride - 1;
+      } else {
+        xm[i] = r; xiy[i] = 0; xix[i] = 0;
+      }
+    } else {
+      xm[i] = -1; xiy[i] = 0; xix[i] = 0;
+    }
+  }
+  // weight rows (permuted so each lane owns consecutive output channels)
+  int64_t wofs[WI];    // element offset of the weight row, or -1
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int R = lrow0 + i * LROW_STEP;           // LDS row in weight tile
+    const int wv = R / (TN * 16);
+    const int rho = R % (TN * 16);
+    const int tn = rho >> 4, r = rho & 15;
+    int n_glob;
+    if (GEGLU) {
+      constexpr int TH = TN / 2;
+      const int t = tn % TH;
+      const int loc = wv * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
+      const int col = block_n0 + loc;
+      n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
+    } else {
+      const int loc = wv * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
+      const int col = block_n0 + loc;
+      n_glob = (col < p.n) ? col : -1;
+    }
+    wofs[i] = (n_glob >= 0) ? (int64_t)n_glob * p.k : -1;
+  }
+
+  u32x4 xreg[XI], wreg[WI];
+
+  auto load_tiles = [&](int kt) {
+    const int k = kbeg + kt * BK + lchunk * 8;
+    const bool kok = k < kend;
+    // weights
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kok && wofs[i] >= 0) v = dd_ld16(reinterpret_cast<const T*>(p.w) + wofs[i] + k);
+      wreg[i] = v;
+    }
+    // activations
+    if (CONV) {
+      const int tap = k / p.cin;
+      const int ci = k - tap * p.cin;
+      const int ky = tap / 3;
+      const int kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        int iy = xiy[i] + ky, ix = xix[i] + kx;
+        if (kok && xm[i] >= 0 && iy >= 0 && iy < p.hv && ix >= 0 && ix < p.wv) {
+          if (p.upsample) {
+            iy = min((int)floorf(iy * p.scale_h), p.hin - 1);
+            ix = min((int)floorf(ix * p.scale_w), p.win - 1);
+          }
+          const int64_t off = (((int64_t)xm[i] * p.hin + iy) * p.win + ix) * p.cin + ci;
+          v = dd_ld16(reinterpret_cast<const T*>(p.a) + off);
+        }
+        xreg[i] = v;
+      }
+    } else {
+      const bool second = k >= p.k1;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (kok && xm[i] >= 0) {
+          const T* src = second
+              ? reinterpret_cast<const T*>(p.a2) + (int64_t)xm[i] * p.lda2 + (k - p.k1)
+              : reinterpret_cast<const T*>(p.a) + (int64_t)xm[i] * p.lda + k;
+          v = dd_ld16(src);
+        }
+        xreg[i] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    T* xs = Xs + buf * BM * BK;
+    T* ws = Ws + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int R = lrow0 + i * LROW_STEP;
+      dd_st16(xs + R * BK + ((lchunk ^ ((R >> 1) & 7)) << 3), xreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int R = lrow0 + i * LROW_STEP;
+      dd_st16(ws + R * BK + ((lchunk ^ ((R >> 1) & 7)) << 3), wreg[i]);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: LDS row = base + (lane & 15); chunk = (lane >> 4) + 4*ks, swizzled
+  const int frow = lane & 15;
+  const int fswz = (lane >> 1) & 7;     // == ((row >> 1) & 7) because tile bases are multiples of 16
+  const int fchunk = lane >> 4;
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const T* xs = Xs + buf * BM * BK + (wave_m * TM * 16 + frow) * BK;
+    const T* ws = Ws + buf * BN * BK + (wave_n * TN * 16 + frow) * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
+      V8 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[i], xf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  // acc[tn][tm][reg]: output row = tile row tm*16 + (lane & 15),
+  //                   output col = q*(4*TN) + tn*4 + reg  (q = lane >> 4)   [non-GEGLU]
+  const int q = lane >> 4;
+  const int c = lane & 15;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = block_m0 + wave_m * (TM * 16) + tm * 16 + c;
+    if (row >= p.rows) continue;
+    if (GEGLU) {
+      constexpr int TH = TN / 2;
+      const int col0 = block_n0 + wave_n * (TH * 16) + q * (4 * TH);
+#pragma unroll
+      for (int g8 = 0; g8 < TH / 2; ++g8) {
+        const int col = col0 + g8 * 8;
+        if (col >= p.n) continue;
+        float h[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          h[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+          g[e] = acc[TH + g8 * 2 + (e >> 2)][tm][e & 3];
+        }
+        if (p.bias) {
+          float b[8];
+          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + col), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] += b[e];
+          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + p.n + col), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] += b[e];
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = h[e] * dd_gelu_erf_f(g[e]);
+        dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
+      }
+    } else {
+      const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
+#pragma unroll
+      for (int g8 = 0; g8 < TN / 2; ++g8) {
+        const int col = col0 + g8 * 8;
+        if (col >= p.n) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+        if (p.partial) {
+          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
+          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          epilogue_store8<T>(p, row, col, v);
+        }
+      }
+    }
+  }
+}
+
+// split-K: sum the fp32 partial slabs and run the fused epilogue.
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_splitk_reduce_kernel(const GemmParams p, int nsplit) {
+  const int64_t groups_per_row = p.n / 8;
+  const int64_t total = (int64_t)p.rows * groups_per_row;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(g / groups_per_row);
+    const int col = (int)(g - (int64_t)row * groups_per_row) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < nsplit; ++z) {
+      const float* src = p.partial + ((int64_t)z * p.rows + row) * p.n + col;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    epilogue_store8<T>(p, row, col, v);
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------
+struct TileCfg { int id, wm, wn, tm, tn; const char* name; };
+constexpr TileCfg kTiles[] = {
+    {1, 2, 2, 4, 4, "128x128"},
+    {2, 2, 2, 4, 2, "128x64"},
+    {3, 2, 2, 2, 4, "64x128"},
+    {4, 2, 2, 2, 2, "64x64"},
+    {5, 4, 2, 4, 4, "256x128"},
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+inline int tile_bm(const TileCfg& t) { return t.wm * t.tm * 16; }
+inline int tile_bn(const TileCfg& t) { return t.wn * t.tn * 16; }
+
+constexpr int kNumCU = 256;
+
+struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; };
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+Plan make_plan(const dd_gemm_desc* d) {
+  const bool geglu = d->epilogue == DD_EPI_GEGLU;
+  Plan pl{};
+  int ti = -1;
+  if (d->tile > 0) {
+    for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == d->tile) ti = i;
+  }
+  if (ti < 0) {
+    // heuristic: biggest tile that still yields >= ~1.5 waves of blocks; else smaller tiles.
+    const int order[] = {0, 1, 2, 3};
+    ti = 3;
+    for (int oi = 0; oi < 4; ++oi) {
+      const TileCfg& t = kTiles[order[oi]];
+      if (geglu && t.tn % 4 != 0) continue;
+      const int bn_out = geglu ? tile_bn(t) / 2 : tile_bn(t);
+      const long blocks = (long)ceil_div(d->rows, tile_bm(t)) * ceil_div(d->n, bn_out);
+      if (blocks >= (long)kNumCU * 3 / 2) { ti = order[oi]; break; }
+      if (oi == 3) ti = geglu ? 2 : 3;
+    }
+    if (geglu && kTiles[ti].tn % 4 != 0) ti = 2;
+  }
+  const TileCfg& t = kTiles[ti];
+  const int bn_out = geglu ? tile_bn(t) / 2 : tile_bn(t);
+  pl.tile_idx = ti;
+  pl.tiles_m = ceil_div(d->rows, tile_bm(t));
+  pl.tiles_n = ceil_div(d->n, bn_out);
+  int split = d->split_k;
+  const int nkt = ceil_div(d->k, BK);
+  if (split <= 0) {
+    split = 1;
+    const long blocks = (long)pl.tiles_m * pl.tiles_n;
+    if (!geglu && blocks < kNumCU && nkt >= 16) {
+      split = (int)((2L * kNumCU + blocks - 1) / blocks);
+      if (split > nkt / 4) split = nkt / 4;
+      if (split > 32) split = 32;
+      if (split < 1) split = 1;
+    }
+  }
+  if (geglu) split = 1;
+  if (split > nkt) split = nkt;
+  int kts = ceil_div(nkt, split);
+  split = ceil_div(nkt, kts);
+  pl.split = split;
+  pl.k_per_split = kts * BK;
+  return pl;
+}
+
+template <typename T, int WM, int WN, int TM, int TN, bool CONV, bool GEGLU>
+int launch_cfg(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(T);
+  auto kern = dd_gemm_kernel<T, WM, WN, TM, TN, CONV, GEGLU>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
+  return dd_check_launch();
+}
+
+template <typename T, bool CONV, bool GEGLU>
+int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  switch (kTiles[pl.tile_idx].id) {
+    case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
+    case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
+    case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
+    case 2: if constexpr (!GEGLU) return launch_cfg<T, 2, 2, 4, 2, CONV, false>(p, pl, s); break;
+    case 4: if constexpr (!GEGLU) return launch_cfg<T, 2, 2, 2, 2, CONV, false>(p, pl, s); break;
+  }
+  return DD_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t s) {
+  int rc;
+  if (d->epilogue == DD_EPI_GEGLU) {
+    if (d->conv) return DD_ERR_UNSUPPORTED;
+    rc = launch_tile<T, false, true>(p, pl, s);
+  } else if (d->conv) {
+    rc = launch_tile<T, true, false>(p, pl, s);
+  } else {
+    rc = launch_tile<T, false, false>(p, pl, s);
+  }
+  if (rc != DD_OK) return rc;
+  if (pl.split > 1) {
+    const int64_t total = (int64_t)p.rows * (p.n / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    GemmParams pr = p;
+    hipLaunchKernelGGL(dd_splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, pr, pl.split);
+    rc = dd_check_launch();
+  }
+  return rc;
+}
+
+int validate(const dd_gemm_desc* d) {
+  if (!d || !d->a || !d->w || !d->out) return DD_ERR_BAD_ARG;
+  if (d->rows <= 0 || d->n <= 0 || d->k <= 0) return DD_ERR_BAD_ARG;
+  if ((d->k & 7) || (d->n & 7) || (d->ldc & 7)) return DD_ERR_BAD_ARG;
+  if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(d->a) || !dd_aligned16(d->w) || !dd_aligned16(d->out)) return DD_ERR_BAD_ARG;
+  if (d->bias && !dd_aligned16(d->bias)) return DD_ERR_BAD_ARG;
+  if (d->res && (!dd_aligned16(d->res) || (d->ldres & 7))) return DD_ERR_BAD_ARG;
+  if (d->rowvec && (!dd_aligned16(d->rowvec) || (d->ld_rowvec & 7) || d->rows_per_inst <= 0)) return DD_ERR_BAD_ARG;
+  if (d->conv) {
+    if (d->a2) return DD_ERR_UNSUPPORTED;
+    if (d->cin <= 0 || (d->cin & 7) || d->k != 9 * d->cin) return DD_ERR_BAD_ARG;
+    if (d->hin <= 0 || d->win <= 0 || d->hout <= 0 || d->wout <= 0) return DD_ERR_BAD_ARG;
+    if (d->stride != 1 && d->stride != 2) return DD_ERR_UNSUPPORTED;
+    if (d->hv <= 0 || d->wv <= 0) return DD_ERR_BAD_ARG;
+    if (d->rows % (d->hout * d->wout) != 0) return DD_ERR_BAD_ARG;
+    if ((d->hv + 2 - 3) / d->stride + 1 != d->hout || (d->wv + 2 - 3) / d->stride + 1 != d->wout) return DD_ERR_BAD_ARG;
+  } else {
+    if (d->lda & 7) return DD_ERR_BAD_ARG;
+    if (d->a2) {
+      if (!dd_aligned16(d->a2) || (d->lda2 & 7) || (d->k1 & 7) || d->k1 <= 0 || d->k1 >= d->k) return DD_ERR_BAD_ARG;
+    }
+  }
+  if (d->epilogue != DD_EPI_NONE && d->epilogue != DD_EPI_GEGLU && d->epilogue != DD_EPI_SILU) return DD_ERR_BAD_ARG;
+  if (d->epilogue == DD_EPI_GEGLU && (d->res || d->rowvec || d->accumulate || d->alpha != 1.0f)) return DD_ERR_UNSUPPORTED;
+  return DD_OK;
+}
+
+thread_local char g_kname[160];
+
+}  // namespace
+
+extern "C" int dd_gemm_num_tiles(void) { return kNumTiles; }
+
+extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
+  if (validate(d) != DD_OK) return 0;
+  const Plan pl = make_plan(d);
+  if (pl.split <= 1) return 0;
+  return (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
+}
+
+extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
+  if (validate(d) != DD_OK) return "invalid";
+  const Plan pl = make_plan(d);
+  snprintf(g_kname, sizeof(g_kname), "dd_gemm_kernel<%s,%s,%s%s> split=%d grid=%dx%d",
+           d->dtype == DD_F16 ? "f16" : "bf16", kTiles[pl.tile_idx].name,
+           d->conv ? "conv3x3" : "dense", d->epilogue == DD_EPI_GEGLU ? ",geglu" : "",
+           pl.split, pl.tiles_m, pl.tiles_n);
+  return g_kname;
+}
+
+extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
+  const int vc = validate(d);
+  if (vc != DD_OK) return vc;
+  const Plan pl = make_plan(d);
+  GemmParams p{};
+  p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
+  p.k1 = d->a2 ? d->k1 : d->k;
+  p.rows = d->rows; p.n = d->n; p.k = d->k;
+  p.w = d->w; p.bias = d->bias; p.rowvec = d->rowvec;
+  p.rows_per_inst = d->rows_per_inst > 0 ? d->rows_per_inst : 1; p.ld_rowvec = d->ld_rowvec;
+  p.res = d->res; p.ldres = d->ldres; p.out = d->out; p.ldc = d->ldc;
+  p.alpha = d->alpha; p.accumulate = d->accumulate;
+  p.act = d->epilogue == DD_EPI_SILU ? DD_EPI_SILU : DD_EPI_NONE;
+  p.hin = d->hin; p.win = d->win; p.cin = d->cin; p.hv = d->hv; p.wv = d->wv;
+  p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;
+  p.upsample = d->conv && (d->hv != d->hin || d->wv != d->win);
+  // torch nearest: src = min(floor(dst * (in/out)), in-1) with a float scale
+  p.scale_h = d->conv ? (float)d->hin / (float)d->hv : 1.f;
+  p.scale_w = d->conv ? (float)d->win / (float)d->wv : 1.f;
+  p.k_per_split = pl.k_per_split;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.partial = nullptr;
+  if (pl.split > 1) {
+    const int64_t need = (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
+    if (!d->ws || d->ws_bytes < need) return DD_ERR_WORKSPACE;
+    p.partial = reinterpret_cast<float*>(d->ws);
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == DD_F16) return launch_dtype<_Float16>(d, p, pl, s);
+  return launch_dtype<__bf16>(d, p, pl, s);
+}

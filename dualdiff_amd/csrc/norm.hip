@@ -1,0 +1,252 @@
+// GroupNorm(+SiLU) in NHWC and LayerNorm for gfx950 — HBM-bound kernels:
+// 16-byte coalesced channel-contiguous loads, fp32 statistics, wave shuffles + LDS for the
+// reductions, one read for statistics + one read/one write for the apply pass (the second
+// read is served from L2 / Infinity Cache at these tensor sizes).
+#include "dd_common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SPLIT = 64;
+constexpr int GN_MAX_C = 4096;
+
+struct GnParams {
+  const void* x1; const void* x2; int c1, c2, c;
+  const void* gamma; const void* beta; void* y;
+  int m, hw, groups, cpg; float eps; int silu;
+  float* ws;          // [m][nsplit][groups][2]
+  int nsplit, pix_per_split;
+};
+
+// thread -> (pixel lane, channel vector) mapping shared by both passes
+struct GnMap { int cv_count, pl_count, cv, pl; bool active; };
+__device__ __forceinline__ GnMap gn_map(int c) {
+  GnMap mp;
+  mp.cv_count = c >> 3;
+  if (mp.cv_count >= GN_THREADS) {       // several channel vectors per thread, one pixel lane
+    mp.pl_count = 1; mp.cv = threadIdx.x; mp.pl = 0; mp.active = true;
+  } else {
+    mp.pl_count = GN_THREADS / mp.cv_count;
+    mp.cv = threadIdx.x % mp.cv_count;
+    mp.pl = threadIdx.x / mp.cv_count;
+    mp.active = mp.pl < mp.pl_count;
+  }
+  return mp;
+}
+
+template <typename T>
+__device__ __forceinline__ const T* gn_src(const GnParams& p, int64_t row, int ch) {
+  return ch < p.c1 ? reinterpret_cast<const T*>(p.x1) + row * p.c1 + ch
+                   : reinterpret_cast<const T*>(p.x2) + row * p.c2 + (ch - p.c1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS)
+void dd_gn_stats_kernel(const GnParams p) {
+  __shared__ float s_sum[64];   // per-group accumulators (<= 64 groups)
+  __shared__ float s_sq[64];
+  const int split = blockIdx.x, inst = blockIdx.y;
+  if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
+  __syncthreads();
+  const GnMap mp = gn_map(p.c);
+  const int p0 = split * p.pix_per_split;
+  const int p1 = min(p.hw, p0 + p.pix_per_split);
+  if (mp.active) {
+    for (int cv = mp.cv; cv < mp.cv_count; cv += GN_THREADS) {
+      const int ch = cv << 3;
+      float s[8], ss[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+      for (int px = p0 + mp.pl; px < p1; px += mp.pl_count) {
+        float f[8];
+        dd_unpack8<T>(dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px, ch)), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+      }
+      // fold the 8 channels into (at most two) groups, then one LDS atomic per group
+      const int g0 = ch / p.cpg;
+      const int g1 = (ch + 7) / p.cpg;
+      float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool first = (ch + e) / p.cpg == g0;
+        a0 += first ? s[e] : 0.f;  b0 += first ? ss[e] : 0.f;
+        a1 += first ? 0.f : s[e];  b1 += first ? 0.f : ss[e];
+      }
+      atomicAdd(&s_sum[g0], a0); atomicAdd(&s_sq[g0], b0);
+      if (g1 != g0) { atomicAdd(&s_sum[g1], a1); atomicAdd(&s_sq[g1], b1); }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < p.groups) {
+    float* dst = p.ws + (((int64_t)inst * p.nsplit + split) * p.groups + threadIdx.x) * 2;
+    dst[0] = s_sum[threadIdx.x];
+    dst[1] = s_sq[threadIdx.x];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS)
+void dd_gn_apply_kernel(const GnParams p) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int split = blockIdx.x, inst = blockIdx.y;
+  if (threadIdx.x < p.groups) {
+    float s = 0.f, ss = 0.f;
+    const float* src = p.ws + ((int64_t)inst * p.nsplit * p.groups + threadIdx.x) * 2;
+    for (int i = 0; i < p.nsplit; ++i) { s += src[0]; ss += src[1]; src += p.groups * 2; }
+    const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
+    const float mean = s * inv_n;
+    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+    s_mean[threadIdx.x] = mean;
+    s_rstd[threadIdx.x] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  const GnMap mp = gn_map(p.c);
+  if (!mp.active) return;
+  const int p0 = split * p.pix_per_split;
+  const int p1 = min(p.hw, p0 + p.pix_per_split);
+  for (int cv = mp.cv; cv < mp.cv_count; cv += GN_THREADS) {
+    const int ch = cv << 3;
+    float ga[8], be[8], sc[8], sh[8];
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.gamma) + ch), ga);
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.beta) + ch), be);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (ch + e) / p.cpg;
+      sc[e] = s_rstd[g] * ga[e];
+      sh[e] = be[e] - s_mean[g] * sc[e];
+    }
+    for (int px = p0 + mp.pl; px < p1; px += mp.pl_count) {
+      const int64_t row = (int64_t)inst * p.hw + px;
+      float f[8];
+      dd_unpack8<T>(dd_ld16(gn_src<T>(p, row, ch)), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = f[e] * sc[e] + sh[e];
+        f[e] = p.silu ? dd_silu_f(v) : v;
+      }
+      dd_st16(reinterpret_cast<T*>(p.y) + row * p.c + ch, dd_pack8<T>(f));
+    }
+  }
+}
+
+// ---- LayerNorm: one wave per row, row held in registers, two-pass (mean, centred var) ----
+constexpr int LN_MAXV = 4;   // up to 4 x (64 lanes x 8) = 2048 channels
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                         const T* __restrict__ beta, T* __restrict__ y,
+                         int64_t rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = c >> 3;
+  float f[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nv) {
+      dd_unpack8<T>(dd_ld16(x + row * c + v * 8), f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[i][e];
+    }
+  }
+  const float mean = dd_wave_sum(s) / (float)c;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(dd_wave_sum(ss) / (float)c + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nv) {
+      float ga[8], be[8], o[8];
+      dd_unpack8<T>(dd_ld16(gamma + v * 8), ga);
+      dd_unpack8<T>(dd_ld16(beta + v * 8), be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * ga[e] + be[e];
+      dd_st16(y + row * c + v * 8, dd_pack8<T>(o));
+    }
+  }
+}
+
+int gn_plan(int hw, int c, int* pix_per_split) {
+  // enough blocks to fill the chip, but at least a few pixels per pixel-lane
+  const int cv = c / 8;
+  const int pl = cv >= GN_THREADS ? 1 : GN_THREADS / cv;
+  int pps = (hw + GN_MAX_SPLIT - 1) / GN_MAX_SPLIT;
+  const int min_pps = pl * 2;
+  if (pps < min_pps) pps = min_pps;
+  if (pps > hw) pps = hw;
+  *pix_per_split = pps;
+  return (hw + pps - 1) / pps;
+}
+
+}  // namespace
+
+extern "C" int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups) {
+  if (m <= 0 || groups <= 0) return 0;
+  return (int64_t)m * GN_MAX_SPLIT * groups * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int32_t c2,
+                                 const void* gamma, const void* beta, void* y,
+                                 int32_t m, int32_t hw, int32_t groups, float eps,
+                                 int32_t apply_silu, int32_t dtype, void* ws, int64_t ws_bytes,
+                                 dd_stream_t stream) {
+  if (!x1 || !gamma || !beta || !y || !ws) return DD_ERR_BAD_ARG;
+  if (c2 < 0 || (c2 > 0 && !x2)) return DD_ERR_BAD_ARG;
+  const int c = c1 + c2;
+  if (m <= 0 || hw <= 0 || groups <= 0 || groups > 64 || c1 <= 0) return DD_ERR_BAD_ARG;
+  if ((c1 & 7) || (c2 & 7) || c % groups != 0 || c > GN_MAX_C) return DD_ERR_BAD_ARG;
+  if (c / groups < 8) return DD_ERR_UNSUPPORTED;   // a 16-B vector may span at most 2 groups
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(x1) || (x2 && !dd_aligned16(x2)) || !dd_aligned16(y) ||
+      !dd_aligned16(gamma) || !dd_aligned16(beta)) return DD_ERR_BAD_ARG;
+  if (ws_bytes < dd_groupnorm_workspace_bytes(m, groups)) return DD_ERR_WORKSPACE;
+  GnParams p{};
+  p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.c = c;
+  p.gamma = gamma; p.beta = beta; p.y = y;
+  p.m = m; p.hw = hw; p.groups = groups; p.cpg = c / groups; p.eps = eps; p.silu = apply_silu;
+  p.ws = reinterpret_cast<float*>(ws);
+  p.nsplit = gn_plan(hw, c, &p.pix_per_split);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(p.nsplit, m);
+  if (dtype == DD_F16) {
+    hipLaunchKernelGGL(dd_gn_stats_kernel<_Float16>, grid, dim3(GN_THREADS), 0, s, p);
+    hipLaunchKernelGGL(dd_gn_apply_kernel<_Float16>, grid, dim3(GN_THREADS), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(dd_gn_stats_kernel<__bf16>, grid, dim3(GN_THREADS), 0, s, p);
+    hipLaunchKernelGGL(dd_gn_apply_kernel<__bf16>, grid, dim3(GN_THREADS), 0, s, p);
+  }
+  return dd_check_launch();
+}
+
+extern "C" int dd_layernorm(const void* x, const void* gamma, const void* beta, void* y,
+                            int64_t rows, int32_t c, float eps, int32_t dtype,
+                            dd_stream_t stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || c <= 0) return DD_ERR_BAD_ARG;
+  if ((c & 7) || c > LN_MAXV * 512) return DD_ERR_UNSUPPORTED;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(x) || !dd_aligned16(y) || !dd_aligned16(gamma) || !dd_aligned16(beta)) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  if (dtype == DD_F16) {
+    hipLaunchKernelGGL(dd_layernorm_kernel<_Float16>, dim3(blocks), dim3(256), 0, s,
+                       (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
+                       (_Float16*)y, rows, c, eps);
+  } else {
+    hipLaunchKernelGGL(dd_layernorm_kernel<__bf16>, dim3(blocks), dim3(256), 0, s,
+                       (const __bf16*)x, (const __bf16*)gamma, (const __bf16*)beta,
+                       (__bf16*)y, rows, c, eps);
+  }
+  return dd_check_launch();
+}

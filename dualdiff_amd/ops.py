@@ -1,0 +1,321 @@
+"""Torch-tensor front end of the HIP C-ABI (device memory + stream plumbing only).
+
+Every function launches hand-written gfx950 kernels from libdualdiff_hip.so on torch's
+current stream.  Tensors are token-major / NHWC 2-D views (rows, channels) in fp16 or bf16.
+There is no eager fallback: a non-GPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import DD_BF16, DD_EPI_GEGLU, DD_EPI_NONE, DD_EPI_SILU, DD_F16, AttnDesc, GemmDesc
+
+_WS = {}
+_WS_MIN_BYTES = 64 << 20
+
+
+def _dt(t):
+    if t.dtype == torch.float16:
+        return DD_F16
+    if t.dtype == torch.bfloat16:
+        return DD_BF16
+    raise TypeError("dualdiff_amd ops take fp16 / bf16 tensors, got %s" % t.dtype)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dualdiff_amd ops run on the GPU only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def workspace(nbytes, device):
+    """Grow-only fp32 scratch buffer per device (allocate before graph capture)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WS.get(key)
+    need = max(int(nbytes), _WS_MIN_BYTES)
+    if ws is None or ws.numel() * 4 < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("workspace would have to grow during graph capture; run one eager "
+                               "warm-up step first")
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _rows2d(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("expected a 2-D tensor with unit inner stride, got shape %s stride %s"
+                         % (tuple(t.shape), t.stride()))
+    return t
+
+
+def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
+         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0):
+    """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused)."""
+    lib = _native.load()
+    _need_gpu(a, w, bias, a2, res, rowvec, out)
+    a = _rows2d(a)
+    w = _rows2d(w)
+    rows = a.shape[0]
+    k = a.shape[1] + (a2.shape[1] if a2 is not None else 0)
+    n_w = w.shape[0]
+    if w.shape[1] != k or not w.is_contiguous():
+        raise ValueError("weight must be contiguous [N, K=%d], got %s" % (k, tuple(w.shape)))
+    n = n_w // 2 if epilogue == DD_EPI_GEGLU else n_w
+    if out is None:
+        out = torch.empty((rows, n), dtype=a.dtype, device=a.device)
+    d = GemmDesc()
+    d.a = a.data_ptr(); d.lda = a.stride(0); d.k1 = a.shape[1]
+    if a2 is not None:
+        a2 = _rows2d(a2)
+        d.a2 = a2.data_ptr(); d.lda2 = a2.stride(0)
+    d.rows, d.n, d.k = rows, n, k
+    d.w = w.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    if rowvec is not None:
+        rowvec = _rows2d(rowvec)
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0); d.rows_per_inst = rows_per_inst
+    if res is not None:
+        res = _rows2d(res)
+        d.res = res.data_ptr(); d.ldres = res.stride(0)
+    out = _rows2d(out)
+    d.out = out.data_ptr(); d.ldc = out.stride(0)
+    d.alpha = alpha; d.accumulate = int(accumulate); d.epilogue = epilogue
+    d.conv = 0
+    d.dtype = _dt(a); d.tile = tile; d.split_k = split_k
+    need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
+    if need > 0:
+        ws = workspace(need, a.device)
+        d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
+    _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
+    return out
+
+
+def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res=None,
+            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0):
+    """3x3 / pad 1 convolution as an implicit GEMM on an NHWC batch.
+
+    x: (m*hin*win, cin); w: (cout, 9*cin) packed [cout][ky][kx][cin]; optional nearest
+    upsample of x to `up_size` first; rowvec: (m, cout) per-instance vector (time embedding).
+    Returns (m*hout*wout, cout)."""
+    lib = _native.load()
+    _need_gpu(x, w, bias, res, rowvec, out)
+    x = _rows2d(x)
+    cin = x.shape[1]
+    if not x.is_contiguous() or x.shape[0] != m * hin * win:
+        raise ValueError("conv input must be contiguous (m*h*w, cin)")
+    hv, wv = (hin, win) if up_size is None else (int(up_size[0]), int(up_size[1]))
+    hout = (hv + 2 - 3) // stride + 1
+    wout = (wv + 2 - 3) // stride + 1
+    cout = w.shape[0]
+    if w.shape[1] != 9 * cin or not w.is_contiguous():
+        raise ValueError("conv weight must be contiguous [cout, 9*cin]")
+    rows = m * hout * wout
+    if out is None:
+        out = torch.empty((rows, cout), dtype=x.dtype, device=x.device)
+    d = GemmDesc()
+    d.a = x.data_ptr(); d.lda = cin; d.k1 = 9 * cin
+    d.rows, d.n, d.k = rows, cout, 9 * cin
+    d.w = w.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    if rowvec is not None:
+        rowvec = _rows2d(rowvec)
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0); d.rows_per_inst = hout * wout
+    if res is not None:
+        res = _rows2d(res)
+        d.res = res.data_ptr(); d.ldres = res.stride(0)
+    out = _rows2d(out)
+    d.out = out.data_ptr(); d.ldc = out.stride(0)
+    d.alpha = alpha; d.accumulate = int(accumulate); d.epilogue = epilogue
+    d.conv = 1
+    d.hin, d.win, d.cin, d.hv, d.wv = hin, win, cin, hv, wv
+    d.hout, d.wout, d.stride = hout, wout, stride
+    d.dtype = _dt(x); d.tile = tile; d.split_k = split_k
+    need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
+    if need > 0:
+        ws = workspace(need, x.device)
+        d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
+    _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
+    return out
+
+
+def groupnorm(x, gamma, beta, m, hw, groups, eps, silu, x2=None, out=None):
+    """GroupNorm (+SiLU) over an NHWC batch; x2 = optional second source concatenated on C."""
+    lib = _native.load()
+    _need_gpu(x, gamma, beta, x2, out)
+    c1 = x.shape[1]
+    c2 = x2.shape[1] if x2 is not None else 0
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("groupnorm inputs must be contiguous")
+    if out is None:
+        out = torch.empty((m * hw, c1 + c2), dtype=x.dtype, device=x.device)
+    need = lib.dd_groupnorm_workspace_bytes(m, groups)
+    ws = workspace(need, x.device)
+    rc = lib.dd_groupnorm_nhwc(_ptr(x), c1, _ptr(x2), c2, _ptr(gamma), _ptr(beta), _ptr(out),
+                               m, hw, groups, eps, int(silu), _dt(x), _ptr(ws), ws.numel() * 4,
+                               _stream())
+    _native.check(rc, "groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    lib = _native.load()
+    _need_gpu(x, gamma, beta, out)
+    x = _rows2d(x)
+    if not x.is_contiguous():
+        raise ValueError("layernorm input must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    rc = lib.dd_layernorm(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1],
+                          eps, _dt(x), _stream())
+    _native.check(rc, "layernorm")
+    return out
+
+
+def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_map=None,
+              out=None, accumulate=False, variant=0):
+    """softmax(scale * q k^T) v per (batch, head).
+
+    q: (batch*lq, >= heads*head_dim) row-strided view; k, v: (kv_batches*lk, ...) likewise, so
+    slices of a fused QKV projection can be passed without copies.  kv_batch_map (int32 device
+    tensor [batch]) redirects batch b to K/V of another batch (neighbour views)."""
+    lib = _native.load()
+    _need_gpu(q, k, v, out, kv_batch_map)
+    q, k, v = _rows2d(q), _rows2d(k), _rows2d(v)
+    if out is None:
+        out = torch.empty((batch * lq, heads * head_dim), dtype=q.dtype, device=q.device)
+    out = _rows2d(out)
+    d = AttnDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.q_batch_stride = lq * q.stride(0)
+    d.k_batch_stride = lk * k.stride(0)
+    d.v_batch_stride = lk * v.stride(0)
+    d.o_batch_stride = lq * out.stride(0)
+    d.batch, d.heads, d.head_dim, d.lq, d.lk = batch, heads, head_dim, lq, lk
+    d.scale = float(scale) if scale is not None else head_dim ** -0.5
+    d.kv_batch_map = kv_batch_map.data_ptr() if kv_batch_map is not None else None
+    d.accumulate = int(accumulate)
+    d.dtype = _dt(q)
+    d.variant = variant
+    _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
+    return out
+
+
+def add(a, b, c=None, out=None):
+    lib = _native.load()
+    _need_gpu(a, b, c, out)
+    if out is None:
+        out = torch.empty_like(a)
+    rc = lib.dd_add(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _dt(a), _stream())
+    _native.check(rc, "add")
+    return out
+
+
+def scale(x, s, out=None):
+    lib = _native.load()
+    _need_gpu(x, out)
+    if out is None:
+        out = torch.empty_like(x)
+    _native.check(lib.dd_scale(_ptr(x), _ptr(out), s, x.numel(), _dt(x), _stream()), "scale")
+    return out
+
+
+def silu(x, out=None):
+    lib = _native.load()
+    _need_gpu(x, out)
+    if out is None:
+        out = torch.empty_like(x)
+    _native.check(lib.dd_silu(_ptr(x), _ptr(out), x.numel(), _dt(x), _stream()), "silu")
+    return out
+
+
+def nchw_to_nhwc(x, c_pad=None):
+    """(m, c, h, w) contiguous -> (m*h*w, c_pad) with zero-padded channels."""
+    lib = _native.load()
+    _need_gpu(x)
+    m, c, h, w = x.shape
+    c_pad = c if c_pad is None else c_pad
+    x = x.contiguous()
+    out = torch.empty((m * h * w, c_pad), dtype=x.dtype, device=x.device)
+    rc = lib.dd_nchw_to_nhwc(_ptr(x), _ptr(out), m, c, h * w, c_pad, _dt(x), _stream())
+    _native.check(rc, "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, m, c, h, w):
+    """(m*h*w, ld>=c) -> (m, c, h, w) contiguous."""
+    lib = _native.load()
+    _need_gpu(x)
+    x = _rows2d(x)
+    out = torch.empty((m, c, h, w), dtype=x.dtype, device=x.device)
+    rc = lib.dd_nhwc_to_nchw(_ptr(x), _ptr(out), m, c, h * w, x.stride(0), _dt(x), _stream())
+    _native.check(rc, "nhwc_to_nchw")
+    return out
+
+
+def timestep_embedding(t, dim, dtype, flip_sin_to_cos=True, freq_shift=0.0, out=None):
+    """t: fp32 device tensor [n] -> (n, dim) sinusoidal embedding in `dtype`."""
+    lib = _native.load()
+    _need_gpu(t, out)
+    if t.dtype != torch.float32:
+        raise TypeError("timesteps must be fp32")
+    n = t.numel()
+    if out is None:
+        out = torch.empty((n, dim), dtype=dtype, device=t.device)
+    rc = lib.dd_timestep_embedding(_ptr(t), _ptr(out), n, dim, int(flip_sin_to_cos), freq_shift,
+                                   _dt(out), _stream())
+    _native.check(rc, "timestep_embedding")
+    return out
+
+
+def conv3x3_small_cout(x, w, bias, m, h, wd, out=None):
+    """conv_out: x (m*h*wd, cin) NHWC, w (cout<=8, 9*cin) -> (m, cout, h, wd) NCHW."""
+    lib = _native.load()
+    _need_gpu(x, w, bias, out)
+    cin = x.shape[1]
+    cout = w.shape[0]
+    if out is None:
+        out = torch.empty((m, cout, h, wd), dtype=x.dtype, device=x.device)
+    rc = lib.dd_conv3x3_small_cout(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), m, h, wd, cin, cout,
+                                   _dt(x), _stream())
+    _native.check(rc, "conv3x3_small_cout")
+    return out
+
+
+def cfg_ddim_step(eps, x, coef, guidance, x_out=None, x_dup=None):
+    """eps: (2, n...) uncond first; x: (n...); coef: fp32 device [4]."""
+    lib = _native.load()
+    _need_gpu(eps, x, coef, x_out, x_dup)
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    rc = lib.dd_cfg_ddim_step(_ptr(eps), _ptr(x), _ptr(x_out), _ptr(x_dup), _ptr(coef),
+                              float(guidance), x.numel(), _dt(x), _stream())
+    _native.check(rc, "cfg_ddim_step")
+    return x_out
+
+
+def gemm_kernel_name(rows, n, k, dtype=torch.bfloat16, conv=False, cin=0, hw=(0, 0)):
+    """Name/plan string of the kernel dd_gemm picks for a shape (profile matching)."""
+    lib = _native.load()
+    d = GemmDesc()
+    dummy = 16
+    d.a = d.w = d.out = dummy
+    d.rows, d.n, d.k, d.k1 = rows, n, k, k
+    d.lda, d.ldc = k, n
+    d.alpha = 1.0
+    d.dtype = DD_F16 if dtype == torch.float16 else DD_BF16
+    if conv:
+        d.conv = 1
+        d.cin = cin; d.hin = d.hv = d.hout = hw[0]; d.win = d.wv = d.wout = hw[1]; d.stride = 1
+    return lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()

@@ -1,0 +1,214 @@
+/*
+ * dualdiff_hip.h — C-ABI of the MI355X (gfx950) denoising hot path.
+ *
+ * Every entry point is a plain `extern "C"` launcher: device pointers + sizes + a
+ * hipStream_t (passed as void*).  Launchers never allocate, never synchronise and
+ * never throw: they validate arguments, enqueue kernels on `stream` and return 0
+ * or a negative DD_ERR_* code.  All scratch memory is caller-owned (`ws`).
+ * Launchers are graph-capture safe (hipGraph / torch.cuda.graph).
+ *
+ * The reference (yangzhaojason/DualDiff, MD_txt_con_fusion/) has no FFI: its hot
+ * path reaches cuDNN/cuBLAS/xformers through torch.nn modules built by
+ * diffusers-0.17.1.  Each launcher below names the reference call site whose
+ * arithmetic it replaces (file:line relative to MD_txt_con_fusion/).
+ *
+ * Layout convention: activations are token-major / NHWC, i.e. a feature map
+ * (M, C, H, W) is stored as rows = M*H*W, cols = C, row stride `ld*` in elements.
+ * dtype: DD_F16 (reference eval dtype, misc/test_utils.py:98) or DD_BF16.
+ * Accumulation, normalisation statistics and softmax are fp32.
+ */
+#ifndef DUALDIFF_HIP_H
+#define DUALDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_ABI_VERSION 1
+
+enum { DD_F16 = 0, DD_BF16 = 1 };
+
+enum {
+  DD_OK = 0,
+  DD_ERR_BAD_ARG = -1,     /* null pointer / non-positive size / misaligned */
+  DD_ERR_UNSUPPORTED = -2, /* shape or option not implemented by the kernels */
+  DD_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after launch */
+  DD_ERR_WORKSPACE = -4    /* caller workspace too small */
+};
+
+typedef void* dd_stream_t; /* hipStream_t */
+
+int dd_abi_version(void);
+const char* dd_error_string(int code);
+/* Reports the compile-time gfx target string ("gfx950"). */
+const char* dd_target_arch(void);
+
+/* ------------------------------------------------------------------------- *
+ * GEMM / implicit-GEMM convolution with fused epilogue.
+ *
+ *   out[r, n] (op)= alpha * ( sum_k A[r, k] * W[n, k] + bias[n]
+ *                             + rowvec[r / rows_per_inst, n] ) + res[r, n]
+ *
+ * Replaces: every nn.Linear / 1x1 nn.Conv2d / 3x3 nn.Conv2d on the path —
+ *   attention to_q/to_k/to_v/to_out        networks/box_adapter.py:102-110,163
+ *   SFA projections                        networks/txt_con_fusion.py:110-116,169
+ *   attn4 + connector                      networks/blocks.py:203-220
+ *   ResnetBlock2D conv1/conv2/shortcut, Down/Upsample2D conv, proj_in/proj_out,
+ *   FeedForward (GEGLU)                    diffusers-0.17.1 (instantiated at
+ *                                          networks/unet_addon_rawbox.py:240-295,
+ *                                          networks/unet_2d_condition_multiview.py:181-216)
+ *   zero convs + conditioning_scale + branch sum
+ *                                          networks/unet_addon_rawbox.py:1029-1055,
+ *                                          pipeline/pipeline_bev_controlnet.py:421-429
+ *   ControlNetConditioningEmbedding convs  networks/map_embedder.py:114-138
+ *
+ * W is [N][K] row-major (torch Linear layout; conv weights pre-packed to
+ * [Cout][ky][kx][Cin]).  K % 8 == 0, N % 8 == 0, all pointers 16-byte aligned,
+ * lda/ldc/ldres multiples of 8.
+ * ------------------------------------------------------------------------- */
+enum { DD_EPI_NONE = 0, DD_EPI_GEGLU = 1, DD_EPI_SILU = 2 };
+
+typedef struct dd_gemm_desc {
+  /* A operand (dense mode): rows x K, row stride lda.  Optional second source
+   * concatenated along K (K = k1 + k2): columns [0,k1) from a, [k1,K) from a2. */
+  const void* a;
+  const void* a2;    /* may be NULL */
+  int64_t lda, lda2;
+  int32_t k1;        /* == K when a2 == NULL */
+  /* Problem size */
+  int32_t rows, n, k;
+  /* Weights / epilogue operands */
+  const void* w;       /* [n_w][k]; n_w = n (or 2n for DD_EPI_GEGLU) */
+  const void* bias;    /* [n_w] or NULL */
+  const void* rowvec;  /* [rows/rows_per_inst][ld_rowvec] or NULL (time-emb add) */
+  int32_t rows_per_inst, ld_rowvec;
+  const void* res;     /* [rows][ldres] or NULL */
+  int64_t ldres;
+  void* out;           /* [rows][ldc] */
+  int64_t ldc;
+  float alpha;         /* see formula */
+  int32_t accumulate;  /* 1: out += value (read-modify-write), 0: out = value */
+  int32_t epilogue;    /* DD_EPI_*; GEGLU: out[r,n] = h * gelu_erf(g) with h = col n,
+                          g = col n + N of the 2N-wide product (FeedForward/GEGLU) */
+  /* conv mode (conv != 0): A is an NHWC image batch and K = 9*cin (3x3, pad 1).
+   * Optional nearest-neighbour upsample of the input to (hv, wv) before the conv
+   * (Upsample2D with explicit output size,
+   *  networks/unet_2d_condition_multiview.py:369-374,500-501). */
+  int32_t conv;        /* 0 dense, 1 conv3x3 */
+  int32_t hin, win, cin;   /* stored input image */
+  int32_t hv, wv;          /* virtual (post-upsample) input size; == hin,win if none */
+  int32_t hout, wout, stride;
+  /* dtype / tuning */
+  int32_t dtype;       /* DD_F16 / DD_BF16 */
+  int32_t tile;        /* 0 = auto, else tile-config id (see dd_gemm_num_tiles) */
+  int32_t split_k;     /* 0 = auto, 1 = off, >1 = number of K slices */
+  void* ws;            /* fp32 workspace for split-K partials */
+  int64_t ws_bytes;
+} dd_gemm_desc;
+
+int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
+/* Workspace bytes dd_gemm needs for this descriptor (0 when split-K is off). */
+int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d);
+int dd_gemm_num_tiles(void);
+/* Name of the kernel symbol dd_gemm would launch for `d` (for profile matching). */
+const char* dd_gemm_kernel_name(const dd_gemm_desc* d);
+
+/* ------------------------------------------------------------------------- *
+ * GroupNorm (+ optional SiLU), NHWC, optional channel-concat of two sources.
+ *   y[m, p, c] = act( (x[m,p,c] - mean[m,g]) * rstd[m,g] * gamma[c] + beta[c] )
+ * Replaces torch.nn.GroupNorm + SiLU inside ResnetBlock2D (eps 1e-5), the
+ * Transformer2DModel input norm (eps 1e-6, no SiLU) and conv_norm_out
+ * (networks/unet_2d_condition_multiview.py:519-522).
+ * ws: fp32 scratch, >= dd_groupnorm_workspace_bytes(M, G).
+ * C1 + C2 = C, C % G == 0, C1 % 8 == 0, C2 % 8 == 0.
+ * ------------------------------------------------------------------------- */
+int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int32_t c2,
+                      const void* gamma, const void* beta, void* y,
+                      int32_t m, int32_t hw, int32_t groups, float eps,
+                      int32_t apply_silu, int32_t dtype, void* ws, int64_t ws_bytes,
+                      dd_stream_t stream);
+int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups);
+
+/* LayerNorm over the last dim (eps 1e-5, affine) — BasicTransformerBlock
+ * norm1/2/3 (diffusers) and norm4 (networks/blocks.py:67-71,191-194). */
+int dd_layernorm(const void* x, const void* gamma, const void* beta, void* y,
+                 int64_t rows, int32_t c, float eps, int32_t dtype, dd_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Scaled-dot-product attention, flash-style (online softmax, fp32 state).
+ *   O[b, i, h, :] (op)= softmax_j( scale * Q[b,i,h,:].K[kb,j,h,:] ) V[kb,j,h,:]
+ * with kb = kv_batch_map ? kv_batch_map[b] : b.
+ * Replaces xformers.ops.memory_efficient_attention at
+ *   networks/box_adapter.py:150-156 (attn1/attn2 processor),
+ *   networks/txt_con_fusion.py:156-162 (SFA), :313-318 (SFA+),
+ *   networks/blocks.py:203-217 (attn4: one call per neighbour with
+ *   accumulate=1 realises the sum over neighbours).
+ * No mask (attention_mask is None on the inference path, blocks.py:166-187).
+ * Q/K/V/O are (batch, len, heads*head_dim) views with row strides ld* (elements),
+ * so they may alias slices of a fused QKV projection.  head_dim in {40,80,160}.
+ * ------------------------------------------------------------------------- */
+typedef struct dd_attn_desc {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t ldq, ldk, ldv, ldo;         /* row strides in elements */
+  int64_t q_batch_stride, k_batch_stride, v_batch_stride, o_batch_stride;
+  int32_t batch, heads, head_dim, lq, lk;
+  float scale;
+  const int32_t* kv_batch_map;        /* device ptr [batch] or NULL */
+  int32_t accumulate;                 /* 1: O += result */
+  int32_t dtype;
+  int32_t variant;                    /* 0 = default (tr-read V), 1 = plain LDS reads */
+} dd_attn_desc;
+
+int dd_attention(const dd_attn_desc* d, dd_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Small HBM-bound helpers.
+ * ------------------------------------------------------------------------- */
+/* y = a + b (+ c)   — ControlNet residual add into UNet skips
+ * (networks/unet_2d_condition_multiview.py:464-473,487-488). c may be NULL. */
+int dd_add(const void* a, const void* b, const void* c, void* y, int64_t n,
+           int32_t dtype, dd_stream_t stream);
+/* y = x * s (in place allowed) */
+int dd_scale(const void* x, void* y, float s, int64_t n, int32_t dtype, dd_stream_t stream);
+/* SiLU elementwise (time embedding act). */
+int dd_silu(const void* x, void* y, int64_t n, int32_t dtype, dd_stream_t stream);
+
+/* NCHW <-> NHWC (only at the 4-channel latent / drop-in boundary). */
+int dd_nchw_to_nhwc(const void* x, void* y, int32_t m, int32_t c, int32_t hw,
+                    int32_t c_pad, int32_t dtype, dd_stream_t stream);
+int dd_nhwc_to_nchw(const void* x, void* y, int32_t m, int32_t c, int32_t hw,
+                    int32_t ldx, int32_t dtype, dd_stream_t stream);
+
+/* Sinusoidal timestep embedding, diffusers `Timesteps(dim, flip_sin_to_cos=True,
+ * downscale_freq_shift=0)` (networks/unet_addon_rawbox.py:142-144,921-927;
+ * unet_2d_condition_multiview.py:404-409): out[i, :] = [cos(t_i f), sin(t_i f)],
+ * f_j = exp(-ln(10000) j / (dim/2)).  t: fp32 device array [n]. */
+int dd_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
+                          int32_t flip_sin_to_cos, float freq_shift,
+                          int32_t dtype, dd_stream_t stream);
+
+/* conv3x3 with tiny Cout (conv_out 320->4): y NCHW fp32/T. x NHWC (rows, cin),
+ * w [cout][9*cin]; writes y as NCHW (m, cout, h, w) in dtype T.
+ * (networks/unet_2d_condition_multiview.py:522) */
+int dd_conv3x3_small_cout(const void* x, const void* w, const void* bias, void* y_nchw,
+                          int32_t m, int32_t h, int32_t wd, int32_t cin, int32_t cout,
+                          int32_t dtype, dd_stream_t stream);
+
+/* Classifier-free guidance + DDIM (eta = 0) update, fused:
+ *   eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);
+ *   x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+ * (pipeline/pipeline_bev_controlnet.py:487-499 with diffusers DDIMScheduler.step).
+ * eps: [2][n] (uncond first, :489), x / x_out: [n] in dtype T; coef: device fp32[4] =
+ * {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} read at kernel time so the
+ * launch can be replayed from a graph. x_dup: optional second copy of x' (the CFG
+ * duplicate `torch.cat([latents]*2)`, :384-386) or NULL. */
+int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, void* x_dup,
+                     const float* coef, float guidance, int64_t n,
+                     int32_t dtype, dd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUALDIFF_HIP_H */

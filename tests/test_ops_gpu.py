@@ -1,0 +1,278 @@
+"""Kernel-level parity: every HIP kernel (through the C-ABI) vs the CPU leaf-op oracle.
+
+Tolerances: outputs are compared in fp32 against the fp32 oracle evaluated on the same
+fp16/bf16-rounded inputs.  The only rounding the kernel may add is the final store, so
+|y - ref| <= TOL[dtype] * max(|ref|) elementwise with TOL = 2^-10 (fp16) / 2^-7 (bf16)
+(one ulp of the storage type at the tensor's scale, plus fp32 summation-order noise).
+"""
+import pytest
+import torch
+
+from oracle import leaf_ops as L
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def rnd(shape, dtype, seed, scale=1.0, device="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(device)
+
+
+def check(y, ref, dtype, what, tol_mult=1.0):
+    y = y.detach().float().cpu()
+    ref = ref.float()
+    assert y.shape == ref.shape, (what, y.shape, ref.shape)
+    assert torch.isfinite(y).all(), what + ": non-finite output"
+    err = (y - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    rel = err / scale
+    print("%-40s max|err|=%.3e  rel-to-max=%.3e" % (what, err, rel))
+    assert rel <= TOL[dtype] * tol_mult, "%s: rel err %.3e > %.3e" % (what, rel, TOL[dtype] * tol_mult)
+
+
+@pytest.fixture(scope="module")
+def ops(gpu):
+    from dualdiff_amd import ops as O
+    return O
+
+
+# ------------------------------------------------------------------ MFMA layout sanity ----
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric W catches any row/col swap in the fragment maps."""
+    n = 128
+    a = torch.eye(n, dtype=torch.float16, device="cuda")
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 61 - 30).to(torch.float16).cuda()
+    y = ops.gemm(a, w, tile=1)
+    check(y, w.float().cpu().t(), torch.float16, "gemm A=I")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("rows,n,k", [(256, 256, 256), (200, 320, 320), (77, 72, 200), (1400, 320, 2880)])
+def test_gemm_tiles(ops, dtype, tile, rows, n, k):
+    a = rnd((rows, k), dtype, 1)
+    w = rnd((n, k), dtype, 2, 0.05)
+    b = rnd((n,), dtype, 3)
+    y = ops.gemm(a, w, b, tile=tile)
+    check(y, L.linear_ref(a, w, b), dtype, "gemm tile%d %dx%dx%d" % (tile, rows, n, k))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogue_full(ops, dtype):
+    rows, n, k = 12 * 91, 640, 1280
+    a = rnd((rows, 768), dtype, 1)
+    a2 = rnd((rows, k - 768), dtype, 11)
+    w = rnd((n, k), dtype, 2, 0.03)
+    b = rnd((n,), dtype, 3)
+    res = rnd((rows, n), dtype, 4)
+    rv = rnd((12, n), dtype, 5)
+    y = ops.gemm(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5)
+    ref = L.linear_ref(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5)
+    check(y, ref, dtype, "gemm concat+bias+rowvec+alpha+res")
+    # accumulate into an existing output, strided output (column slice of a wider buffer)
+    buf = rnd((rows, 2 * n), dtype, 6)
+    prev = buf[:, n:].clone()
+    ops.gemm(a, w, b, a2=a2, out=buf[:, n:], accumulate=True)
+    # accumulate adds the storage-rounded previous value; one extra rounding -> 2x tol
+    check(buf[:, n:], L.linear_ref(a, w, b, a2=a2) + prev.float().cpu(), dtype, "gemm accumulate strided", 2.0)
+    y = ops.gemm(a, w[:, :768].contiguous(), b, epilogue=ops.DD_EPI_SILU)
+    check(y, L.linear_ref(a, w[:, :768], b, silu=True), dtype, "gemm silu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c", [(1400, 320), (350, 640), (91 * 3, 1280)])
+def test_gemm_geglu(ops, dtype, rows, c):
+    a = rnd((rows, c), dtype, 1)
+    w = rnd((8 * c, c), dtype, 2, 0.05)
+    b = rnd((8 * c,), dtype, 3)
+    y = ops.gemm(a, w, b, epilogue=ops.DD_EPI_GEGLU)
+    check(y, L.linear_ref(a, w, b, geglu=True), dtype, "geglu %dx%d" % (rows, c), 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("split", [0, 2, 5])
+def test_gemm_split_k(ops, dtype, split):
+    rows, n, k = 336, 1280, 2560
+    a = rnd((rows, k), dtype, 1)
+    w = rnd((n, k), dtype, 2, 0.02)
+    b = rnd((n,), dtype, 3)
+    res = rnd((rows, n), dtype, 4)
+    y = ops.gemm(a, w, b, res=res, split_k=split)
+    check(y, L.linear_ref(a, w, b, res=res), dtype, "gemm split_k=%d" % split)
+
+
+# ------------------------------------------------------------------------------ conv ----
+CONV_CASES = [
+    # m, hin, win, cin, cout, stride, up_size
+    (2, 28, 50, 320, 320, 1, None),
+    (2, 28, 50, 320, 320, 2, None),
+    (3, 14, 25, 640, 640, 2, None),
+    (3, 7, 13, 1280, 1280, 2, None),
+    (2, 4, 7, 1280, 1280, 1, (7, 13)),
+    (2, 7, 13, 1280, 1280, 1, (14, 25)),
+    (1, 14, 25, 640, 640, 1, (28, 50)),
+    (2, 28, 50, 960, 320, 1, None),
+    (12, 4, 7, 2560, 1280, 1, None),        # deep level -> split-K
+    (2, 28, 50, 8, 320, 1, None),           # conv_in, latent channels padded 4 -> 8
+    (1, 56, 100, 16, 32, 2, None),          # condition embedder style convs
+    (1, 28, 50, 96, 256, 2, None),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3x3(ops, dtype, case):
+    m, hin, win, cin, cout, stride, up = case
+    x = rnd((m * hin * win, cin), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, hin, win, stride=stride, up_size=up)
+    ref = L.conv3x3_ref(x, w, b, m, hin, win, stride=stride, up_size=up)
+    check(y, ref, dtype, "conv %s" % (case,))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_resnet_epilogue(ops, dtype):
+    """conv + bias + per-instance time-embedding vector + residual (ResnetBlock2D conv1/conv2)."""
+    m, h, w_, cin, cout = 3, 14, 25, 640, 640
+    x = rnd((m * h * w_, cin), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    temb = rnd((m, cout), dtype, 4)
+    res = rnd((m * h * w_, cout), dtype, 5)
+    y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, rowvec=temb, res=res)
+    ref = L.conv3x3_ref(x, w, b, m, h, w_) + temb.float().cpu().repeat_interleave(h * w_, 0) + res.float().cpu()
+    check(y, ref, dtype, "conv resnet epilogue")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_out_small(ops, dtype):
+    m, h, w_, cin, cout = 2, 28, 50, 320, 4
+    x = rnd((m * h * w_, cin), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    y = ops.conv3x3_small_cout(x, L.pack_conv_weight(w), b, m, h, w_)
+    ref = L.conv3x3_ref(x, w, b, m, h, w_).reshape(m, h, w_, cout).permute(0, 3, 1, 2)
+    check(y, ref, dtype, "conv_out 320->4 (NCHW out)")
+
+
+# ----------------------------------------------------------------------------- norms ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,hw,c1,c2,silu,eps", [
+    (3, 1400, 320, 0, True, 1e-5), (2, 350, 640, 0, False, 1e-6), (2, 91, 1280, 0, True, 1e-5),
+    (2, 1400, 640, 320, True, 1e-5), (2, 350, 1280, 640, True, 1e-5), (3, 28, 1280, 1280, True, 1e-5),
+    (2, 91, 1280, 640, True, 1e-5), (1, 1400, 320, 320, True, 1e-5)])
+def test_groupnorm(ops, dtype, m, hw, c1, c2, silu, eps):
+    x1 = rnd((m * hw, c1), dtype, 1) + 0.5
+    x2 = rnd((m * hw, c2), dtype, 2, 2.0) if c2 else None
+    g = rnd((c1 + c2,), dtype, 3) + 1.0
+    b = rnd((c1 + c2,), dtype, 4)
+    y = ops.groupnorm(x1, g, b, m, hw, 32, eps, silu, x2=x2)
+    ref = L.groupnorm_ref(x1, g, b, m, hw, 32, eps, silu, x2=x2)
+    check(y, ref, dtype, "groupnorm m%d hw%d c%d+%d silu=%s" % (m, hw, c1, c2, silu), 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c", [(1400 * 2, 320), (701, 640), (91, 1280)])
+def test_layernorm(ops, dtype, rows, c):
+    x = rnd((rows, c), dtype, 1) * 3 + 1
+    g = rnd((c,), dtype, 2) + 1.0
+    b = rnd((c,), dtype, 3)
+    check(ops.layernorm(x, g, b), L.layernorm_ref(x, g, b), dtype, "layernorm %dx%d" % (rows, c), 2.0)
+
+
+# ------------------------------------------------------------------------- attention ----
+ATTN_CASES = [
+    # batch, lq, lk, heads, d
+    (2, 1400, 1400, 8, 40), (3, 350, 350, 8, 80), (3, 91, 91, 8, 160), (6, 28, 28, 8, 160),
+    (2, 1400, 98, 8, 40), (2, 350, 78, 8, 80), (2, 91, 98, 8, 160), (2, 1400, 77, 8, 40),
+    (1, 17, 1, 8, 40), (1, 130, 65, 2, 80),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[str(c) for c in ATTN_CASES])
+def test_attention(ops, dtype, variant, case):
+    b, lq, lk, h, d = case
+    c = h * d
+    q = rnd((b * lq, c), dtype, 1)
+    k = rnd((b * lk, c), dtype, 2)
+    v = rnd((b * lk, c), dtype, 3)
+    y = ops.attention(q, k, v, b, lq, lk, h, d, variant=variant)
+    # P is rounded to the storage type before the PV product (as flash kernels do): 4x tol
+    check(y, L.attention_ref(q, k, v, b, lq, lk, h, d), dtype, "attention %s v%d" % (case, variant), 4.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_fused_qkv_and_neighbours(ops, dtype):
+    """Strided q/k/v views of one fused [rows, 3C] projection + kv_batch_map + accumulate
+    (the attn4 pattern: out = Attn(q_v, kv_left) + Attn(q_v, kv_right))."""
+    b, l, h, d = 6, 350, 8, 80
+    c = h * d
+    qkv = rnd((b * l, 3 * c), dtype, 1)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    left = torch.tensor([5, 0, 1, 2, 3, 4], dtype=torch.int32, device="cuda")
+    right = torch.tensor([1, 2, 3, 4, 5, 0], dtype=torch.int32, device="cuda")
+    out = ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left)
+    ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=right, out=out, accumulate=True)
+    ref = (L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=left)
+           + L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=right))
+    check(out, ref, dtype, "attn4 neighbour sum", 6.0)
+
+
+def test_attention_softmax_spike(ops):
+    """Force the online-softmax rescale branch: one key dominates late in the sequence."""
+    b, lq, lk, h, d = 1, 64, 300, 8, 40
+    dtype = torch.float16
+    q = rnd((b * lq, h * d), dtype, 1)
+    k = rnd((b * lk, h * d), dtype, 2)
+    v = rnd((b * lk, h * d), dtype, 3)
+    k[250] = q[7] * 4.0
+    y = ops.attention(q, k, v, b, lq, lk, h, d)
+    check(y, L.attention_ref(q, k, v, b, lq, lk, h, d), dtype, "attention spike", 4.0)
+
+
+# ----------------------------------------------------------------------- elementwise ----
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(ops, dtype):
+    a, b, c = rnd((1400 * 320,), dtype, 1), rnd((1400 * 320,), dtype, 2), rnd((1400 * 320,), dtype, 3)
+    check(ops.add(a, b), a.float().cpu() + b.float().cpu(), dtype, "add2")
+    check(ops.add(a, b, c), a.float().cpu() + b.float().cpu() + c.float().cpu(), dtype, "add3")
+    check(ops.scale(a, 0.37), a.float().cpu() * 0.37, dtype, "scale")
+    check(ops.silu(a), torch.nn.functional.silu(a.float().cpu()), dtype, "silu")
+    x = rnd((3, 4, 28, 50), dtype, 4)
+    y = ops.nchw_to_nhwc(x, 8)
+    ref = torch.zeros(3 * 1400, 8)
+    ref[:, :4] = x.float().cpu().permute(0, 2, 3, 1).reshape(-1, 4)
+    check(y, ref, dtype, "nchw->nhwc pad8")
+    z = ops.nhwc_to_nchw(y, 3, 4, 28, 50)
+    check(z, x.float().cpu(), dtype, "nhwc->nchw")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding(ops, dtype):
+    t = torch.tensor([981.0, 1.0, 500.0, 0.0], device="cuda")
+    y = ops.timestep_embedding(t, 320, dtype)
+    check(y, L.timestep_embedding_ref(t, 320), dtype, "timestep embedding", 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cfg_ddim(ops, dtype):
+    n = 6 * 4 * 28 * 50
+    eps = rnd((2, n), dtype, 1)
+    x = rnd((n,), dtype, 2)
+    coef = torch.tensor([0.9, 0.4359, 0.95, 0.3122], device="cuda")
+    dup = torch.empty((2, n), dtype=dtype, device="cuda")
+    y = ops.cfg_ddim_step(eps, x, coef, 2.0, x_dup=dup[1])
+    ref = L.cfg_ddim_ref(eps, x, coef.cpu(), 2.0)
+    check(y, ref, dtype, "cfg+ddim", 3.0)
+    assert torch.equal(dup[1], y)
+
+
+def test_fails_loudly_on_cpu_tensor(ops):
+    with pytest.raises(RuntimeError):
+        ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))
