@@ -1,0 +1,146 @@
+"""Seeds, reduced configurations and seeded inputs of the golden-vector cases.
+
+Shared by tests/golden/mint.py (which runs the reference source on them) and
+tests/test_oracle_golden.py (which runs the oracle on them).  Inputs are regenerated from seeds;
+only the reference OUTPUTS are stored (tests/golden/*.npz).  No reference code here.
+"""
+import torch
+
+from oracle.init_utils import seeded_tensor
+
+SEED_SFA, SEED_EMB, SEED_BOX, SEED_PROC, SEED_BLOCK, SEED_UNET, SEED_CNET = 11, 12, 13, 14, 15, 16, 17
+
+# configs/dataset/Nuscenes.yaml:27-33
+VIEW_PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+
+H, W = 28, 50           # 224x400 / 8
+N_CAM = 6
+
+
+def sfa_inputs():
+    return seeded_tensor((6, 320, H, W), 101), seeded_tensor((6, 77, 768), 102)
+
+
+def cond_image():
+    g = torch.Generator().manual_seed(103)
+    return torch.rand((1, 3, 224, 2400), generator=g)
+
+
+def box_inputs():
+    g = torch.Generator().manual_seed(104)
+    bb = (torch.rand((12, 5, 8, 3), generator=g) - 0.5) * 100.0
+    cl = torch.randint(0, 10, (12, 5), generator=g)
+    mk = torch.rand((12, 5), generator=g) > 0.3
+    return bb, cl, mk
+
+
+def proc_inputs():
+    return seeded_tensor((3, 140, 320), 105), seeded_tensor((3, 13, 768), 106)
+
+
+def block_kwargs():
+    return dict(dim=64, num_attention_heads=8, attention_head_dim=8, cross_attention_dim=48)
+
+
+def block_inputs():
+    return seeded_tensor((12, 35, 64), 107), seeded_tensor((12, 9, 48), 108)
+
+
+def unet_kwargs():
+    return dict(block_out_channels=(32, 64, 128, 128), cross_attention_dim=64, attention_head_dim=8)
+
+
+def unet_inputs():
+    m = N_CAM
+    sample = seeded_tensor((m, 4, H, W), 109)
+    t = torch.tensor(481)
+    ctx = seeded_tensor((m, 11, 64), 110)
+    shapes = [(32, 28, 50)] * 3 + [(32, 14, 25)] + [(64, 14, 25)] * 2 + [(64, 7, 13)] + \
+             [(128, 7, 13)] * 2 + [(128, 4, 7)] * 3
+    down = [seeded_tensor((m,) + s, 200 + i, 0.5) for i, s in enumerate(shapes)]
+    mid = seeded_tensor((m, 128, 4, 7), 230, 0.5)
+    return sample, t, ctx, down, mid
+
+
+def controlnet_kwargs():
+    """Constructor kwargs for the REFERENCE class (diffusers-style names)."""
+    return {
+        "diffusers": dict(in_channels=4, block_out_channels=(320, 64, 128, 128), layers_per_block=2,
+                          cross_attention_dim=768, attention_head_dim=8, norm_num_groups=32,
+                          camera_in_dim=189, camera_out_dim=768, uncond_cam_in_dim=(3, 7),
+                          conditioning_embedding_out_channels=(16, 32, 96, 256), drop_cond_ratio=0.0),
+        "cond_channels": (16, 32, 96, 256),
+    }
+
+
+def controlnet_oracle_kwargs():
+    return dict(in_channels=4, block_out_channels=(320, 64, 128, 128), layers_per_block=2,
+                cross_attention_dim=768, attention_head_dim=8, use_txt_con_fusion=True)
+
+
+def controlnet_inputs(occ3d):
+    """b = 2 scenes (so the (b n) flattening order matters), 6 views, per-scene timesteps."""
+    b = 2
+    g = torch.Generator().manual_seed(300 + int(occ3d))
+    inp = {
+        "sample": seeded_tensor((b, N_CAM, 4, H, W), 301),
+        "timestep": torch.tensor([981, 41]),
+        "camera_param": seeded_tensor((b, N_CAM, 3, 7), 302),
+        "encoder_hidden_states": seeded_tensor((b, 9, 768), 303),
+        "conditioning_scale": 0.75,
+    }
+    n_box_views = 1 if occ3d else N_CAM       # fg branch shares boxes over views (bbox_view_shared)
+    inp["bboxes_3d_data"] = {
+        "bboxes": (torch.rand((b, n_box_views, 4, 8, 3), generator=g) - 0.5) * 100.0,
+        "classes": torch.randint(0, 10, (b, n_box_views, 4), generator=g),
+        "masks": torch.rand((b, n_box_views, 4), generator=g) > 0.3,
+    }
+    if occ3d:   # ORS-3D class ids / 17 (dataset/utils.py:417-420)
+        inp["controlnet_cond"] = torch.randint(0, 18, (b * N_CAM, 320, H, W), generator=g).float() / 17.0
+    else:       # ORS panorama image
+        inp["controlnet_cond"] = torch.rand((b, 3, 224, 2400), generator=g)
+    return inp
+
+
+MAX_STORED = 16384
+
+
+def compact(key, t):
+    """Golden-fixture encoding of one fp32 tensor: full tensor when small, else an evenly
+    strided subsample of the flattened tensor + float64 checksums of the whole tensor."""
+    import numpy as np
+    flat = t.reshape(-1)
+    n = flat.numel()
+    if n <= MAX_STORED:
+        return {key: flat.numpy().reshape(tuple(t.shape))}
+    stride = (n + MAX_STORED - 1) // MAX_STORED
+    stride += 1 - stride % 2            # odd stride: walks across rows / channels
+    return {key + "__sub": flat[::stride].numpy(), key + "__stride": np.int64(stride),
+            key + "__shape": np.asarray(t.shape, dtype=np.int64),
+            key + "__sum": np.float64(flat.double().sum().item()),
+            key + "__abssum": np.float64(flat.double().abs().sum().item())}
+
+
+def compare(npz, key, t, rtol, atol):
+    """Checks tensor `t` against the fixture entry `key`; returns the max abs error seen."""
+    import numpy as np
+    t = t.detach().float()
+    if key in npz.files:
+        ref = torch.from_numpy(npz[key])
+        assert tuple(ref.shape) == tuple(t.shape), (key, ref.shape, t.shape)
+        err = (t - ref).abs().max().item()
+        assert torch.allclose(t, ref, rtol=rtol, atol=atol), "%s: max err %g" % (key, err)
+        return err
+    assert tuple(npz[key + "__shape"]) == tuple(t.shape), (key, npz[key + "__shape"], t.shape)
+    stride = int(npz[key + "__stride"])
+    flat = t.reshape(-1)
+    ref = torch.from_numpy(npz[key + "__sub"])
+    sub = flat[::stride]
+    err = (sub - ref).abs().max().item()
+    assert torch.allclose(sub, ref, rtol=rtol, atol=atol), "%s: max err %g" % (key, err)
+    n = flat.numel()
+    s, a = flat.double().sum().item(), flat.double().abs().sum().item()
+    tol = atol * n ** 0.5 * 4 + rtol * float(npz[key + "__abssum"])
+    assert abs(s - float(npz[key + "__sum"])) <= tol, (key, "sum", s, float(npz[key + "__sum"]))
+    assert abs(a - float(npz[key + "__abssum"])) <= tol, (key, "abssum")
+    return err
