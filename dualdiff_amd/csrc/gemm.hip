@@ -513,10 +513,12 @@ extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
 extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   if (validate(d) != DD_OK) return "invalid";
   const Plan pl = make_plan(d);
-  snprintf(g_kname, sizeof(g_kname), "dd_gemm_kernel<%s,%s,%s%s> split=%d grid=%dx%d",
-           d->dtype == DD_F16 ? "f16" : "bf16", kTiles[pl.tile_idx].name,
-           d->conv ? "conv3x3" : "dense", d->epilogue == DD_EPI_GEGLU ? ",geglu" : "",
-           pl.split, pl.tiles_m, pl.tiles_n);
+  const TileCfg& t = kTiles[pl.tile_idx];
+  // demangled template-argument form, as rocprofv3 prints the kernel symbol
+  snprintf(g_kname, sizeof(g_kname), "dd_gemm_kernel<%s, %d, %d, %d, %d, %s, %s> split=%d grid=%dx%d tile=%s",
+           d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn,
+           d->conv ? "true" : "false", d->epilogue == DD_EPI_GEGLU ? "true" : "false",
+           pl.split, pl.tiles_m, pl.tiles_n, t.name);
   return g_kname;
 }
 

@@ -43,16 +43,20 @@ __device__ __forceinline__ const T* gn_src(const GnParams& p, int64_t row, int c
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS)
 void dd_gn_stats_kernel(const GnParams p) {
-  __shared__ float s_sum[64];   // per-group accumulators (<= 64 groups)
-  __shared__ float s_sq[64];
+  // Deterministic (fixed-order) reduction: every thread publishes the partial sums of the (at most
+  // two) groups its 8-channel vector touches; one thread per group then adds them in thread order.
+  __shared__ float s_a0[GN_THREADS], s_b0[GN_THREADS], s_a1[GN_THREADS], s_b1[GN_THREADS];
+  __shared__ int s_g0[GN_THREADS], s_g1[GN_THREADS];
   const int split = blockIdx.x, inst = blockIdx.y;
-  if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
-  __syncthreads();
   const GnMap mp = gn_map(p.c);
   const int p0 = split * p.pix_per_split;
   const int p1 = min(p.hw, p0 + p.pix_per_split);
-  if (mp.active) {
-    for (int cv = mp.cv; cv < mp.cv_count; cv += GN_THREADS) {
+  float gsum = 0.f, gsq = 0.f;          // owned by thread g < groups
+  for (int cv0 = 0; cv0 < mp.cv_count; cv0 += GN_THREADS) {
+    const int cv = cv0 + mp.cv;
+    int g0 = -1, g1 = -1;
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+    if (mp.active && cv < mp.cv_count) {
       const int ch = cv << 3;
       float s[8], ss[8];
 #pragma unroll
@@ -63,25 +67,32 @@ void dd_gn_stats_kernel(const GnParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
       }
-      // fold the 8 channels into (at most two) groups, then one LDS atomic per group
-      const int g0 = ch / p.cpg;
-      const int g1 = (ch + 7) / p.cpg;
-      float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+      g0 = ch / p.cpg;
+      const int gl = (ch + 7) / p.cpg;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const bool first = (ch + e) / p.cpg == g0;
         a0 += first ? s[e] : 0.f;  b0 += first ? ss[e] : 0.f;
         a1 += first ? 0.f : s[e];  b1 += first ? 0.f : ss[e];
       }
-      atomicAdd(&s_sum[g0], a0); atomicAdd(&s_sq[g0], b0);
-      if (g1 != g0) { atomicAdd(&s_sum[g1], a1); atomicAdd(&s_sq[g1], b1); }
+      g1 = gl != g0 ? gl : -1;
     }
+    s_g0[threadIdx.x] = g0; s_a0[threadIdx.x] = a0; s_b0[threadIdx.x] = b0;
+    s_g1[threadIdx.x] = g1; s_a1[threadIdx.x] = a1; s_b1[threadIdx.x] = b1;
+    __syncthreads();
+    if (threadIdx.x < p.groups) {
+      const int g = threadIdx.x;
+      for (int t = 0; t < GN_THREADS; ++t) {
+        if (s_g0[t] == g) { gsum += s_a0[t]; gsq += s_b0[t]; }
+        if (s_g1[t] == g) { gsum += s_a1[t]; gsq += s_b1[t]; }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x < p.groups) {
     float* dst = p.ws + (((int64_t)inst * p.nsplit + split) * p.groups + threadIdx.x) * 2;
-    dst[0] = s_sum[threadIdx.x];
-    dst[1] = s_sq[threadIdx.x];
+    dst[0] = gsum;
+    dst[1] = gsq;
   }
 }
 

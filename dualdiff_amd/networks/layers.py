@@ -1,0 +1,585 @@
+"""Building blocks of the denoising UNet / ControlNet on the HIP C-ABI (NHWC, fused epilogues).
+
+The classes carry the *parameter names and constructor arguments* of the diffusers-0.17.1
+modules the reference instantiates (so diffusers-layout checkpoints load with
+`load_state_dict`), but the arithmetic is dispatched to the gfx950
+kernels in libdualdiff_hip.so through `dualdiff_amd.ops` — there is no torch.nn.functional
+compute on this path and no CPU fallback.
+
+Activations travel as token-major 2-D tensors (m*h*w, c) plus the (m, h, w) triple; NCHW exists
+only at the 4-channel latent boundary and when a caller hands in NCHW residuals.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops as O
+
+
+# ----------------------------------------------------------------------------- helpers ----
+class _Cached(nn.Module):
+    """Module with lazily packed kernel-layout weights; caches drop on .to()/load_state_dict."""
+
+    def _drop_cache(self):
+        for k in [k for k in self.__dict__ if k.startswith("_pk_")]:
+            del self.__dict__[k]
+
+    def _apply(self, fn, *a, **k):
+        self._drop_cache()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._drop_cache()
+        return super()._load_from_state_dict(*a, **k)
+
+
+def _pad_cols(w, mult=8):
+    k = w.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return w.contiguous()
+    out = w.new_zeros((w.shape[0], kp))
+    out[:, :k] = w
+    return out
+
+
+def to_nhwc(x):
+    """(m, c, h, w) tensor -> ((m*h*w, c) view/copy, m, h, w); zero-copy for channels_last."""
+    m, c, h, w = x.shape
+    p = x.permute(0, 2, 3, 1)
+    if not p.is_contiguous():
+        if c % 8 == 0 or not x.is_cuda:
+            p = p.contiguous()
+        else:
+            return O.nchw_to_nhwc(x), m, h, w
+    return p.reshape(m * h * w, c), m, h, w
+
+
+def as_nchw_view(x2d, m, h, w):
+    """Zero-copy logical-NCHW (channels_last strides) view of an NHWC activation."""
+    return x2d.view(m, h, w, x2d.shape[1]).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------ linear ----
+class Linear(_Cached):
+    """nn.Linear / 1x1 nn.Conv2d.  `conv` only changes the stored weight shape ([n,k,1,1])."""
+
+    def __init__(self, in_features, out_features, bias=True, conv=False):
+        super().__init__()
+        self.in_features, self.out_features, self.conv = in_features, out_features, conv
+        shape = (out_features, in_features, 1, 1) if conv else (out_features, in_features)
+        self.weight = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+
+    @property
+    def w2d(self):
+        if "_pk_w" not in self.__dict__:
+            self.__dict__["_pk_w"] = _pad_cols(self.weight.detach().reshape(self.out_features, -1))
+        return self.__dict__["_pk_w"]
+
+    def run(self, x2d, **kw):
+        """x2d: (rows, K) — fused-epilogue GEMM (see ops.gemm kwargs)."""
+        w = self.w2d
+        if w.shape[1] != self.in_features:   # K padded to a multiple of 8 (e.g. cam2token 189 -> 192)
+            x2d = torch.nn.functional.pad(x2d, (0, w.shape[1] - x2d.shape[1]))
+        return O.gemm(x2d, w, self.bias, **kw)
+
+    def forward(self, x):
+        """Tensor-in / tensor-out form used by foreign attention processors:
+        (..., K) tokens, or (m, K, h, w) NCHW for the 1x1-conv flavour."""
+        if self.conv and x.dim() == 4:
+            x2d, m, h, w = to_nhwc(x)
+            return as_nchw_view(self.run(x2d), m, h, w)
+        lead = x.shape[:-1]
+        y = self.run(x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x.contiguous().reshape(-1, x.shape[-1]))
+        return y.reshape(*lead, self.out_features)
+
+
+class Conv3x3(_Cached):
+    """nn.Conv2d(k=3, padding=1, stride) as implicit GEMM; weight kept in torch layout
+    [cout, cin, 3, 3] for checkpoints, packed to [cout][ky][kx][cin_pad] for the kernel."""
+
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+
+    @property
+    def cin_pad(self):
+        return (self.in_channels + 7) // 8 * 8
+
+    @property
+    def packed(self):
+        if "_pk_w" not in self.__dict__:
+            w = self.weight.detach().permute(0, 2, 3, 1)              # [cout, 3, 3, cin]
+            if self.cin_pad != self.in_channels:
+                wp = w.new_zeros((self.out_channels, 3, 3, self.cin_pad))
+                wp[..., :self.in_channels] = w
+                w = wp
+            self.__dict__["_pk_w"] = w.reshape(self.out_channels, 9 * self.cin_pad).contiguous()
+        return self.__dict__["_pk_w"]
+
+    def run(self, x2d, m, h, w, up_size=None, **kw):
+        return O.conv3x3(x2d, self.packed, self.bias, m, h, w, stride=self.stride, up_size=up_size, **kw)
+
+    def out_hw(self, h, w, up_size=None):
+        hv, wv = (h, w) if up_size is None else up_size
+        return (hv - 1) // self.stride + 1, (wv - 1) // self.stride + 1
+
+    def forward(self, x):
+        x2d, m, h, w = to_nhwc(x)
+        if x2d.shape[1] != self.cin_pad:
+            x2d = torch.nn.functional.pad(x2d, (0, self.cin_pad - x2d.shape[1]))
+        ho, wo = self.out_hw(h, w)
+        return as_nchw_view(self.run(x2d, m, h, w), m, ho, wo)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.empty(num_channels))
+        self.bias = nn.Parameter(torch.empty(num_channels))
+
+    def run(self, x2d, m, hw, silu, x2=None):
+        return O.groupnorm(x2d, self.weight, self.bias, m, hw, self.num_groups, self.eps, silu, x2=x2)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.empty(dim))
+        self.bias = nn.Parameter(torch.empty(dim))
+
+    def run(self, x2d):
+        return O.layernorm(x2d, self.weight, self.bias, self.eps)
+
+    def forward(self, x):
+        return self.run(x.reshape(-1, x.shape[-1])).reshape(x.shape)
+
+
+class _Dropout(nn.Module):
+    """Placeholder for nn.Dropout(p=0) so that `to_out.1` / `ff.net.1` indices exist."""
+
+    def forward(self, x):
+        return x
+
+
+# --------------------------------------------------------------------------- embeddings ---
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift):
+        super().__init__()
+        self.num_channels, self.flip_sin_to_cos = num_channels, flip_sin_to_cos
+        self.downscale_freq_shift = downscale_freq_shift
+
+    def run(self, t_f32, dtype):
+        return O.timestep_embedding(t_f32, self.num_channels, dtype, self.flip_sin_to_cos,
+                                    float(self.downscale_freq_shift))
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = Linear(in_channels, time_embed_dim)
+        self.linear_2 = Linear(time_embed_dim, time_embed_dim)
+
+    def run(self, t_emb):
+        return self.linear_2.run(self.linear_1.run(t_emb, epilogue=O.DD_EPI_SILU))
+
+
+# ------------------------------------------------------------------------------- resnet ---
+class ResnetBlock2D(nn.Module):
+    """GN+SiLU -> conv3x3 (+bias +time-emb vector in the epilogue) -> GN+SiLU -> conv3x3
+    (+bias +shortcut in the epilogue).  Input may be the channel-concat of two tensors
+    (up path: [h, skip]) which is never materialised."""
+
+    def __init__(self, in_channels, out_channels, temb_channels, groups=32, eps=1e-5):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = GroupNorm(groups, in_channels, eps)
+        self.conv1 = Conv3x3(in_channels, out_channels)
+        self.time_emb_proj = Linear(temb_channels, out_channels)
+        self.norm2 = GroupNorm(groups, out_channels, eps)
+        self.conv2 = Conv3x3(out_channels, out_channels)
+        self.conv_shortcut = Linear(in_channels, out_channels, conv=True) if in_channels != out_channels else None
+
+    def run(self, x, m, h, w, temb_vec, x2=None, extra_res=None):
+        """x: (mhw, c1) [, x2: (mhw, c2)]; temb_vec: (m, cout) = time_emb_proj(SiLU(emb)) view.
+        extra_res: optional second residual added to the output (ControlNet mid residual)."""
+        hw = h * w
+        a = self.norm1.run(x, m, hw, True, x2=x2)
+        hid = self.conv1.run(a, m, h, w, rowvec=temb_vec)
+        a = self.norm2.run(hid, m, hw, True)
+        if self.conv_shortcut is not None:
+            sc = self.conv_shortcut.run(x, a2=x2, res=extra_res)
+        elif extra_res is not None:
+            sc = O.add(x, extra_res)
+        else:
+            sc = x
+        return self.conv2.run(a, m, h, w, res=sc)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = Conv3x3(channels, channels, stride=2)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = Conv3x3(channels, channels)
+
+
+# ---------------------------------------------------------------------------- attention ---
+class HIPAttnProcessor:
+    """Default attention processor: fused QKV / KV projection GEMMs + flash attention kernel +
+    out-projection with the residual folded into its epilogue when the caller provides one.
+    Same call protocol as diffusers processors (box_adapter.py:33-40)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 residual=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is None on the denoising path (blocks.py:166-187)")
+        b, lq, c = hidden_states.shape
+        x = hidden_states.reshape(b * lq, c)
+        res2d = residual.reshape(b * lq, -1) if residual is not None else None
+        if encoder_hidden_states is None:
+            out = attn.run_self(x, b, lq, res=res2d)
+        else:
+            e = encoder_hidden_states
+            out = attn.run_cross(x, b, lq, e.reshape(-1, e.shape[-1]), e.shape[1], res=res2d)
+        return out.reshape(b, lq, -1)
+
+
+class Attention(_Cached):
+    """diffusers `Attention` surface (to_q/to_k/to_v/to_out, heads, scale, processor protocol)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, bias=False):
+        super().__init__()
+        inner = heads * dim_head
+        self.inner_dim, self.heads, self.dim_head = inner, heads, dim_head
+        self.scale = dim_head ** -0.5
+        self.is_cross = cross_attention_dim is not None
+        self.norm_cross = None
+        self.group_norm = None
+        self.spatial_norm = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.to_q = Linear(query_dim, inner, bias=bias)
+        self.to_k = Linear(cross_attention_dim or query_dim, inner, bias=bias)
+        self.to_v = Linear(cross_attention_dim or query_dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim), _Dropout()])
+        self.processor = HIPAttnProcessor()
+
+    def set_processor(self, processor):
+        if isinstance(getattr(self, "processor", None), nn.Module) and not isinstance(processor, nn.Module):
+            self._modules.pop("processor")
+        self.processor = processor
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size=None, out_dim=3):
+        if attention_mask is not None:
+            raise NotImplementedError
+        return None
+
+    def head_to_batch_dim(self, t):
+        b, l, c = t.shape
+        return t.reshape(b, l, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, l, -1)
+
+    def batch_to_head_dim(self, t):
+        bh, l, d = t.shape
+        return t.reshape(bh // self.heads, self.heads, l, d).permute(0, 2, 1, 3).reshape(bh // self.heads, l, -1)
+
+    # fused weights ------------------------------------------------------------------------
+    def _fused(self, names):
+        key = "_pk_" + "".join(names)
+        if key not in self.__dict__:
+            self.__dict__[key] = torch.cat([getattr(self, n).weight.detach() for n in names], dim=0).contiguous()
+        return self.__dict__[key]
+
+    def _drop_cache(self):
+        super()._drop_cache()
+
+    def project_qkv(self, x2d):
+        """One GEMM for Q, K, V of a self-attention style layer -> (rows, 3*inner)."""
+        return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")))
+
+    def project_kv(self, ctx2d):
+        """K and V of the context in one GEMM -> (rows_ctx, 2*inner)."""
+        return O.gemm(ctx2d, self._fused(("to_k", "to_v")))
+
+    def run_self(self, x2d, batch, lq, res=None):
+        c = self.inner_dim
+        qkv = self.project_qkv(x2d)
+        o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, lq, lq, self.heads,
+                        self.dim_head, self.scale)
+        return self.to_out[0].run(o, res=res)
+
+    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None):
+        c = self.inner_dim
+        q = self.to_q.run(x2d)
+        if kv is None:
+            kv = self.project_kv(ctx2d)
+        o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale)
+        return self.to_out[0].run(o, res=res)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **kw)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    """Linear(C, 8C) with the GEGLU gate fused into the GEMM epilogue, then Linear(4C, C) with
+    the residual add fused."""
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), _Dropout(), Linear(dim * mult, dim)])
+
+    def run(self, x2d, res=None):
+        g = self.net[0].proj.run(x2d, epilogue=O.DD_EPI_GEGLU)
+        return self.net[2].run(g, res=res)
+
+
+class BasicTransformerBlock(nn.Module):
+    """Stock block (ControlNet): LN -> self-attn -> + ; LN -> cross-attn -> + ; LN -> FF -> +."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, cross_attention_dim=None, **unused):
+        super().__init__()
+        self.dim = dim
+        self.norm1 = LayerNorm(dim)
+        self.attn1 = Attention(dim, None, num_attention_heads, attention_head_dim)
+        self.norm2 = LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, num_attention_heads, attention_head_dim)
+        self.norm3 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def _attn(self, attn, x_norm, h, batch, l, ctx=None, lc=0):
+        """Runs `attn` (+ residual h).  Foreign processors get (B, L, C) tensors through the
+        diffusers protocol; the built-in one fuses the residual into the out-projection."""
+        if isinstance(attn.processor, HIPAttnProcessor):
+            if ctx is None:
+                return attn.run_self(x_norm, batch, l, res=h)
+            return attn.run_cross(x_norm, batch, l, ctx, lc, res=h)
+        e = None if ctx is None else ctx.reshape(batch, lc, -1)
+        out = attn(x_norm.reshape(batch, l, -1), encoder_hidden_states=e)
+        return O.add(out.reshape(batch * l, -1).contiguous(), h)
+
+    def run(self, h, batch, l, ctx2d, lc):
+        h = self._attn(self.attn1, self.norm1.run(h), h, batch, l)
+        h = self._attn(self.attn2, self.norm2.run(h), h, batch, l, ctx2d, lc)
+        return self.ff.run(self.norm3.run(h), res=h)
+
+
+class Transformer2DModel(nn.Module):
+    """GN(1e-6) -> 1x1 conv -> blocks -> 1x1 conv -> + residual; NHWC makes the token reshapes free."""
+
+    def __init__(self, num_attention_heads, attention_head_dim, in_channels, cross_attention_dim,
+                 norm_num_groups=32, block_cls=BasicTransformerBlock, block_kwargs=None):
+        super().__init__()
+        inner = num_attention_heads * attention_head_dim
+        self.norm = GroupNorm(norm_num_groups, in_channels, eps=1e-6)
+        self.proj_in = Linear(in_channels, inner, conv=True)
+        self.transformer_blocks = nn.ModuleList([
+            block_cls(inner, num_attention_heads, attention_head_dim, cross_attention_dim=cross_attention_dim,
+                      **(block_kwargs or {}))])
+        self.proj_out = Linear(inner, in_channels, conv=True)
+
+    def run(self, x, m, h, w, ctx2d, lc):
+        a = self.norm.run(x, m, h * w, False)
+        t = self.proj_in.run(a)
+        for blk in self.transformer_blocks:
+            t = blk.run(t, m, h * w, ctx2d, lc)
+        return self.proj_out.run(t, res=x)
+
+
+# ------------------------------------------------------------------------------- blocks ---
+class CrossAttnDownBlock2D(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, heads, cross_attention_dim,
+                 add_downsample, groups=32, eps=1e-5, block_cls=BasicTransformerBlock, block_kwargs=None):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels, groups, eps)
+            for i in range(num_layers)])
+        self.attentions = nn.ModuleList([
+            Transformer2DModel(heads, out_channels // heads, out_channels, cross_attention_dim, groups,
+                               block_cls, block_kwargs) for _ in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+
+class DownBlock2D(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, out_channels, temb_channels, num_layers, add_downsample, groups=32, eps=1e-5):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels, groups, eps)
+            for i in range(num_layers)])
+        self.attentions = None
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+
+def run_down_block(blk, x, m, h, w, temb_slices, ctx2d, lc):
+    """-> (x, h, w, [skip tensors with their (h, w)])."""
+    skips = []
+    for i, resnet in enumerate(blk.resnets):
+        x = resnet.run(x, m, h, w, temb_slices[id(resnet)])
+        if blk.attentions is not None:
+            x = blk.attentions[i].run(x, m, h, w, ctx2d, lc)
+        skips.append((x, h, w))
+    if blk.downsamplers is not None:
+        conv = blk.downsamplers[0].conv
+        x = conv.run(x, m, h, w)
+        h, w = conv.out_hw(h, w)
+        skips.append((x, h, w))
+    return x, h, w, skips
+
+
+class UNetMidBlock2DCrossAttn(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, temb_channels, heads, cross_attention_dim, groups=32, eps=1e-5,
+                 block_cls=BasicTransformerBlock, block_kwargs=None):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels, in_channels, temb_channels, groups, eps)
+                                      for _ in range(2)])
+        self.attentions = nn.ModuleList([
+            Transformer2DModel(heads, in_channels // heads, in_channels, cross_attention_dim, groups,
+                               block_cls, block_kwargs)])
+
+    def run(self, x, m, h, w, temb_slices, ctx2d, lc, extra_res=None):
+        x = self.resnets[0].run(x, m, h, w, temb_slices[id(self.resnets[0])])
+        x = self.attentions[0].run(x, m, h, w, ctx2d, lc)
+        return self.resnets[1].run(x, m, h, w, temb_slices[id(self.resnets[1])], extra_res=extra_res)
+
+
+class UpBlock2D(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, temb_channels, num_layers,
+                 add_upsample, groups=32, eps=1e-5):
+        super().__init__()
+        self.resnets = _up_resnets(in_channels, out_channels, prev_output_channel, temb_channels, num_layers, groups, eps)
+        self.attentions = None
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+
+class CrossAttnUpBlock2D(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, num_layers, heads,
+                 cross_attention_dim, add_upsample, groups=32, eps=1e-5, block_cls=BasicTransformerBlock,
+                 block_kwargs=None):
+        super().__init__()
+        self.resnets = _up_resnets(in_channels, out_channels, prev_output_channel, temb_channels, num_layers, groups, eps)
+        self.attentions = nn.ModuleList([
+            Transformer2DModel(heads, out_channels // heads, out_channels, cross_attention_dim, groups,
+                               block_cls, block_kwargs) for _ in range(num_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+
+def _up_resnets(in_channels, out_channels, prev_output_channel, temb_channels, num_layers, groups, eps):
+    rs = []
+    for i in range(num_layers):
+        skip = in_channels if i == num_layers - 1 else out_channels
+        rin = prev_output_channel if i == 0 else out_channels
+        rs.append(ResnetBlock2D(rin + skip, out_channels, temb_channels, groups, eps))
+    return nn.ModuleList(rs)
+
+
+def run_up_block(blk, x, m, h, w, skips, temb_slices, ctx2d, lc, up_size):
+    """skips: list of (tensor, h, w) consumed from the end.  The concat [x, skip] is never
+    materialised: GroupNorm and the 1x1 shortcut read both sources."""
+    for i, resnet in enumerate(blk.resnets):
+        s, sh, sw = skips.pop()
+        assert (sh, sw) == (h, w)
+        x = resnet.run(x, m, h, w, temb_slices[id(resnet)], x2=s)
+        if blk.attentions is not None:
+            x = blk.attentions[i].run(x, m, h, w, ctx2d, lc)
+    if blk.upsamplers is not None:
+        conv = blk.upsamplers[0].conv
+        size = up_size if up_size is not None else (2 * h, 2 * w)
+        x = conv.run(x, m, h, w, up_size=size)      # nearest upsample folded into the conv gather
+        h, w = size
+    return x, h, w
+
+
+class TimeEmbProjBank:
+    """All ResnetBlock2D.time_emb_proj layers of a model evaluated as ONE GEMM per forward
+    (~35 tiny launches -> 1).  Returns {id(resnet): (m, cout) view}."""
+
+    def __init__(self, model):
+        self.resnets = [mod for mod in model.modules() if isinstance(mod, ResnetBlock2D)]
+        self._w = self._b = None
+
+    def invalidate(self):
+        self._w = self._b = None
+
+    def run(self, emb_act):
+        if self._w is None or self._w.dtype != emb_act.dtype or self._w.device != emb_act.device:
+            self._w = torch.cat([r.time_emb_proj.weight.detach() for r in self.resnets], 0).contiguous()
+            self._b = torch.cat([r.time_emb_proj.bias.detach() for r in self.resnets], 0).contiguous()
+        allv = O.gemm(emb_act, self._w, self._b)
+        out, off = {}, 0
+        for r in self.resnets:
+            out[id(r)] = allv[:, off:off + r.out_channels]
+            off += r.out_channels
+        return out
+
+
+def seeded_init_(module, seed=0):
+    """Deterministic name-keyed random initialisation for synthetic-weight runs (bench / smoke):
+    fan-in scaled normals for matrices, ~1 for norm scales, small biases.  Mirrors
+    oracle/init_utils.py so the CPU baseline can be given identical weights, without importing it."""
+    import zlib
+    sd = {}
+    for name, t in module.state_dict().items():
+        if not t.is_floating_point():
+            sd[name] = t
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        if t.dim() >= 2:
+            v = torch.randn(t.shape, generator=g) * (t[0].numel() ** -0.5)
+        elif name.endswith("weight"):
+            v = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+        else:
+            v = 0.05 * torch.randn(t.shape, generator=g)
+        sd[name] = v
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def device_init_(module, seed=0):
+    """Same distributions as seeded_init_, drawn directly on the module's device (fast path for
+    the full-size synthetic-weight benchmark; not bit-reproducible against the CPU generator)."""
+    g = None
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if not t.is_floating_point():
+                continue
+            if g is None or g.device != t.device:
+                g = torch.Generator(device=t.device).manual_seed(seed)
+            if t.dim() >= 2:
+                v = torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32) * (t[0].numel() ** -0.5)
+            elif name.endswith("weight"):
+                v = 1.0 + 0.1 * torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32)
+            else:
+                v = 0.05 * torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32)
+            t.copy_(v.to(t.dtype))
+    for m in module.modules():
+        if hasattr(m, "_drop_cache"):
+            m._drop_cache()
+    if hasattr(module, "_invalidate"):
+        module._invalidate()
+    return module

@@ -1,0 +1,253 @@
+"""`UNet2DConditionModelMultiview` on hand-written gfx950 kernels.
+
+Drop-in for /root/reference/MD_txt_con_fusion/magicdrive/networks/unet_2d_condition_multiview.py
+(class at :44, forward at :327-527): same constructor/config keys, same `forward()` keyword
+names and return type, diffusers-layout state dict (incl. the `norm4 / attn4 / connector`
+additions, blocks.py:67-90), loadable by dotted path
+(`model.unet_module: dualdiff_amd.networks.unet_2d_condition_multiview.UNet2DConditionModelMultiview`).
+
+Internally the network runs NHWC end to end: fused GroupNorm+SiLU, implicit-GEMM 3x3 convs with
+bias / time-embedding / residual epilogues, fused-QKV flash attention, GEGLU in the GEMM epilogue,
+the up-path channel concat and the nearest upsample folded into their consumers.
+"""
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .. import ops as O
+from .blocks import BasicMultiviewTransformerBlock
+from .layers import (Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
+                     TimestepEmbedding, Timesteps, UNetMidBlock2DCrossAttn, UpBlock2D, as_nchw_view,
+                     run_down_block, run_up_block, to_nhwc)
+from .model_base import ModelBase
+
+
+@dataclass
+class UNet2DConditionOutput:
+    sample: torch.Tensor
+
+
+_DEFAULT_PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+
+
+class UNet2DConditionModelMultiview(ModelBase):
+    _WARN_ONCE = 0
+
+    def __init__(
+        self,
+        sample_size: Optional[int] = None,
+        in_channels: int = 4,
+        out_channels: int = 4,
+        center_input_sample: bool = False,
+        flip_sin_to_cos: bool = True,
+        freq_shift: int = 0,
+        down_block_types: Tuple[str] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                        "CrossAttnDownBlock2D", "DownBlock2D"),
+        mid_block_type: Optional[str] = "UNetMidBlock2DCrossAttn",
+        up_block_types: Tuple[str] = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D",
+                                      "CrossAttnUpBlock2D"),
+        only_cross_attention: Union[bool, Tuple[bool]] = False,
+        block_out_channels: Tuple[int] = (320, 640, 1280, 1280),
+        layers_per_block: Union[int, Tuple[int]] = 2,
+        downsample_padding: int = 1,
+        mid_block_scale_factor: float = 1,
+        act_fn: str = "silu",
+        norm_num_groups: Optional[int] = 32,
+        norm_eps: float = 1e-5,
+        cross_attention_dim: Union[int, Tuple[int]] = 1280,
+        attention_head_dim: Union[int, Tuple[int]] = 8,
+        use_linear_projection: bool = False,
+        # parameters added by the reference (unet_2d_condition_multiview.py:173-179)
+        trainable_state="only_new",
+        neighboring_view_pair: Optional[dict] = None,
+        neighboring_attn_type: str = "add",
+        zero_module_type: str = "zero_linear",
+        crossview_attn_type: str = "basic",
+        img_size: Optional[Tuple[int, int]] = None,
+        **other_diffusers_config,
+    ):
+        super().__init__()
+        cfg = dict(locals())
+        for k in ("self", "__class__", "other_diffusers_config"):
+            cfg.pop(k, None)
+        cfg.update(other_diffusers_config)
+        self._register_config(**cfg)
+        # the SD-v1.5 / DualDiff configuration space this implementation covers
+        unsupported = {
+            "act_fn": act_fn != "silu", "use_linear_projection": use_linear_projection,
+            "only_cross_attention": bool(only_cross_attention) and only_cross_attention is not False,
+            "center_input_sample": center_input_sample, "crossview_attn_type": crossview_attn_type != "basic",
+            "mid_block_type": mid_block_type != "UNetMidBlock2DCrossAttn",
+            "class_embed_type": other_diffusers_config.get("class_embed_type") is not None,
+            "addition_embed_type": other_diffusers_config.get("addition_embed_type") is not None,
+            "encoder_hid_dim": other_diffusers_config.get("encoder_hid_dim") is not None,
+            "mid_block_scale_factor": mid_block_scale_factor != 1, "downsample_padding": downsample_padding != 1,
+        }
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError("UNet2DConditionModelMultiview (HIP): unsupported config: %s" % bad)
+        n = len(down_block_types)
+        heads = (attention_head_dim,) * n if isinstance(attention_head_dim, int) else tuple(attention_head_dim)
+        layers = (layers_per_block,) * n if isinstance(layers_per_block, int) else tuple(layers_per_block)
+        xdim = (cross_attention_dim,) * n if isinstance(cross_attention_dim, int) else tuple(cross_attention_dim)
+        self.crossview_attn_type = crossview_attn_type
+        self.img_size = [int(s) for s in img_size] if img_size is not None else None
+        self.trainable_state = trainable_state
+        self._new_module = {}
+        pair = neighboring_view_pair if neighboring_view_pair is not None else _DEFAULT_PAIR
+        blk_kw = dict(neighboring_view_pair=pair, neighboring_attn_type=neighboring_attn_type,
+                      zero_module_type=zero_module_type)
+        bcls = BasicMultiviewTransformerBlock
+
+        c0 = block_out_channels[0]
+        ted = c0 * 4
+        self.conv_in = Conv3x3(in_channels, c0)
+        self.time_proj = Timesteps(c0, flip_sin_to_cos, freq_shift)
+        self.time_embedding = TimestepEmbedding(c0, ted)
+        self.class_embedding = None
+        self.down_blocks = nn.ModuleList()
+        oc = c0
+        for i, t in enumerate(down_block_types):
+            ic, oc = oc, block_out_channels[i]
+            final = i == n - 1
+            if t == "CrossAttnDownBlock2D":
+                self.down_blocks.append(CrossAttnDownBlock2D(ic, oc, ted, layers[i], heads[i], xdim[i], not final,
+                                                             norm_num_groups, norm_eps, bcls, blk_kw))
+            elif t == "DownBlock2D":
+                self.down_blocks.append(DownBlock2D(ic, oc, ted, layers[i], not final, norm_num_groups, norm_eps))
+            else:
+                raise NotImplementedError(t)
+        self.mid_block = UNetMidBlock2DCrossAttn(block_out_channels[-1], ted, heads[-1], xdim[-1],
+                                                 norm_num_groups, norm_eps, bcls, blk_kw)
+        self.up_blocks = nn.ModuleList()
+        self.num_upsamplers = 0
+        rev = list(reversed(block_out_channels))
+        rheads, rlayers, rxd = list(reversed(heads)), list(reversed(layers)), list(reversed(xdim))
+        oc = rev[0]
+        for i, t in enumerate(up_block_types):
+            final = i == n - 1
+            prev, oc = oc, rev[i]
+            ic = rev[min(i + 1, n - 1)]
+            if not final:
+                self.num_upsamplers += 1
+            if t == "CrossAttnUpBlock2D":
+                self.up_blocks.append(CrossAttnUpBlock2D(ic, oc, prev, ted, rlayers[i] + 1, rheads[i], rxd[i],
+                                                         not final, norm_num_groups, norm_eps, bcls, blk_kw))
+            elif t == "UpBlock2D":
+                self.up_blocks.append(UpBlock2D(ic, prev, oc, ted, rlayers[i] + 1, not final,
+                                                norm_num_groups, norm_eps))
+            else:
+                raise NotImplementedError(t)
+        self.conv_norm_out = GroupNorm(norm_num_groups, c0, norm_eps)
+        self.conv_out = Conv3x3(c0, out_channels)
+
+    # -- training-surface stubs (the released reference trains no UNet parameters, :221,233-242) --
+    @property
+    def trainable_module(self) -> Dict[str, nn.Module]:
+        if self.trainable_state == "all":
+            return {self.__class__: self}
+        if self.trainable_state == "only_new":
+            return self._new_module
+        raise ValueError(f"Unknown trainable_state: {self.trainable_state}")
+
+    @property
+    def trainable_parameters(self):
+        return [p for mod in self.trainable_module.values() for p in mod.parameters()]
+
+    @classmethod
+    def from_unet_2d_condition(cls, unet, load_weights_from_unet: bool = True, **kwargs):
+        """unet_2d_condition_multiview.py:294-325: build from a plain SD UNet's config/weights."""
+        model = cls(**{k: v for k, v in dict(unet.config).items() if not k.startswith("_")}, **kwargs)
+        if load_weights_from_unet:
+            model.load_state_dict(unet.state_dict(), strict=False)
+        return model
+
+    # -- forward -----------------------------------------------------------------------------------
+    def _timesteps(self, timestep, m, device):
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)], dtype=torch.float32, device=device)
+        t = t.to(device=device, dtype=torch.float32).reshape(-1)
+        return t.expand(m).contiguous()
+
+    def forward(
+        self,
+        sample: torch.Tensor,
+        timestep: Union[torch.Tensor, float, int],
+        encoder_hidden_states: torch.Tensor,
+        class_labels: Optional[torch.Tensor] = None,
+        timestep_cond: Optional[torch.Tensor] = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+        down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
+        mid_block_additional_residual: Optional[torch.Tensor] = None,
+        return_dict: bool = True,
+    ):
+        """Same contract as the reference forward (:327-339): `sample` (M, 4, h, w) NCHW, `timestep`
+        scalar / 0-d / (M,), `encoder_hidden_states` (M, Lc, 768), optional ControlNet residuals
+        (NCHW-shaped tensors; channels_last strides are consumed zero-copy)."""
+        if attention_mask is not None or timestep_cond is not None or class_labels is not None:
+            raise NotImplementedError("attention_mask / timestep_cond / class_labels are None on the "
+                                      "denoising path (pipeline_bev_controlnet.py:476-484)")
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs is unused by the DualDiff pipeline")
+        if not sample.is_cuda:
+            raise RuntimeError("dualdiff_amd runs on the GPU only; got a %s tensor" % sample.device)
+        dt = self.dtype
+        m = sample.shape[0]
+        x, m, h, w = to_nhwc(sample.to(dt))
+        if x.shape[1] != self.conv_in.cin_pad:
+            x = torch.nn.functional.pad(x, (0, self.conv_in.cin_pad - x.shape[1]))
+        down_res = None
+        if down_block_additional_residuals is not None:
+            down_res = [to_nhwc(r.to(dt))[0] for r in down_block_additional_residuals]
+        mid_res = None
+        if mid_block_additional_residual is not None:
+            mid_res = to_nhwc(mid_block_additional_residual.to(dt))[0]
+        ctx = encoder_hidden_states.to(dt)
+        lc = ctx.shape[1]
+        ctx2d = ctx.reshape(m * lc, ctx.shape[2])
+        if not ctx2d.is_contiguous():
+            ctx2d = ctx2d.contiguous()
+        out = self.forward_nhwc(x, m, h, w, self._timesteps(timestep, m, sample.device), ctx2d, lc,
+                                down_res, mid_res)
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    def forward_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, down_res=None, mid_res=None):
+        """x: (m*h*w, 8) NHWC latents (4 channels zero-padded to 8); residuals: NHWC 2-D tensors in
+        skip order.  Returns eps as (m, 4, h, w) NCHW."""
+        dt = self.dtype
+        # 1. time (unet_2d_condition_multiview.py:404-411)
+        emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
+        temb = self.temb_bank.run(O.silu(emb))
+        # 28 % 8 != 0 -> explicit upsample sizes (:363-374, :500-501)
+        forward_size = any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w))
+        # 2./3. conv_in + down path (:443-462)
+        x = self.conv_in.run(x, m, h, w)
+        skips = [(x, h, w)]
+        for blk in self.down_blocks:
+            x, h, w, s = run_down_block(blk, x, m, h, w, temb, ctx2d, lc)
+            skips += s
+        # ControlNet residual add on the skips (:464-473)
+        if down_res is not None:
+            if len(down_res) != len(skips):
+                raise ValueError("expected %d down-block residuals, got %d" % (len(skips), len(down_res)))
+            skips = [(O.add(s, r), sh, sw) for (s, sh, sw), r in zip(skips, down_res)]
+        # 4. mid (+ residual, :476-488; folded into the last resnet's epilogue)
+        x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc, extra_res=mid_res)
+        # 5. up (:491-516)
+        for i, blk in enumerate(self.up_blocks):
+            final = i == len(self.up_blocks) - 1
+            k = len(blk.resnets)
+            up_size = None
+            if not final:
+                nxt = skips[-k - 1]
+                up_size = (nxt[1], nxt[2]) if forward_size else None
+            x, h, w = run_up_block(blk, x, m, h, w, skips, temb, ctx2d, lc, up_size)
+        # 6. post-process (:519-522): GN + SiLU fused, conv_out writes NCHW directly
+        a = self.conv_norm_out.run(x, m, h * w, True)
+        return O.conv3x3_small_cout(a, self.conv_out.packed, self.conv_out.bias, m, h, w)

@@ -1,0 +1,362 @@
+"""`BEVControlNetModel` (one DualDiff ControlNet branch) on hand-written gfx950 kernels.
+
+Drop-in for /root/reference/MD_txt_con_fusion/magicdrive/networks/unet_addon_rawbox.py
+(class :39, forward :794-1082): same config keys, same `forward()` keywords (incl. the required
+`use_aug_text` kwarg, :812), same post-construction attribute protocol
+(`use_cam_in_temb / use_box_adapter / use_txt_con_fusion(p) / use_occ_3d`, nullable
+`adm_proj / txt_con_fusion(p) / controlnet_cond_embedding`, misc/test_utils.py:123-136), same
+helpers (`uncond_cam_param`, `add_uncond_to_kwargs`, `prepare`), diffusers-layout state dict.
+
+Eval path only: the training-time condition dropout (:380-438, :839-846) is out of scope.
+
+The forward is split in two so a sampler can hoist the step-invariant half:
+  `prepare_condition()` — camera / text / box tokens, ORS condition embedding, SFA;
+  `forward_nhwc()`      — conv_in (+cond in the epilogue), encoder, mid block, 13 zero convs with
+                          `conditioning_scale` and the dual-branch sum folded into their epilogues.
+`forward()` = both, per call, exactly like the reference.
+"""
+import logging
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops as O
+from ..misc.common import load_module
+from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor  # noqa: F401
+from .embedder import get_embedder
+from .layers import (Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
+                     UNetMidBlock2DCrossAttn, as_nchw_view, run_down_block, to_nhwc)
+from .model_base import ModelBase
+from .output_cls import BEVControlNetOutput
+from .txt_con_fusion import txt_con_XFormersAttn, txt_con_XFormersAttn_plus
+
+
+class _Embedding1(nn.Module):
+    """nn.Embedding(1, d) — only `.weight` is ever used (uncond camera, :118-119)."""
+
+    def __init__(self, num, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num, dim))
+
+
+class _AdmProj(nn.Module):
+    """Placeholder holding the reference's `adm_proj` parameters (Linear, SiLU, Linear; :299-303)
+    so checkpoints load strictly; `use_cam_in_temb` is asserted off by the reference itself (:954)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("0", Linear(cin, cout))
+        self.add_module("2", Linear(cout, cout))
+
+
+class BEVControlNetModel(ModelBase):
+    _keys_to_ignore_on_load_missing = ("adm_proj", "txt_con_fusion", "txt_con_fusionp")
+
+    def __init__(
+        self,
+        in_channels: int = 4,
+        flip_sin_to_cos: bool = True,
+        freq_shift: int = 0,
+        down_block_types: Tuple[str] = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                        "CrossAttnDownBlock2D", "DownBlock2D"),
+        only_cross_attention: Union[bool, Tuple[bool]] = False,
+        block_out_channels: Tuple[int] = (320, 640, 1280, 1280),
+        layers_per_block: int = 2,
+        downsample_padding: int = 1,
+        mid_block_scale_factor: float = 1,
+        act_fn: str = "silu",
+        norm_num_groups: Optional[int] = 32,
+        norm_eps: float = 1e-5,
+        cross_attention_dim: int = 1280,
+        attention_head_dim: Union[int, Tuple[int]] = 8,
+        use_linear_projection: bool = False,
+        class_embed_type: Optional[str] = None,
+        num_class_embeds: Optional[int] = None,
+        upcast_attention: bool = False,
+        resnet_time_scale_shift: str = "default",
+        projection_class_embeddings_input_dim: Optional[int] = None,
+        controlnet_conditioning_channel_order: str = "rgb",
+        conditioning_embedding_out_channels: Optional[Tuple[int]] = None,
+        global_pool_conditions: bool = False,
+        # BEV params
+        uncond_cam_in_dim: Tuple[int, int] = (3, 7),
+        camera_in_dim: int = 189,
+        camera_out_dim: int = 768,
+        map_embedder_cls: str = None,
+        map_embedder_param: dict = None,
+        map_size: Tuple[int, int, int] = None,
+        use_uncond_map: str = None,
+        drop_cond_ratio: float = 0.0,
+        drop_cam_num: int = 1,
+        drop_cam_with_box: bool = False,
+        cam_embedder_param: Optional[Dict] = None,
+        bbox_embedder_cls: str = None,
+        bbox_embedder_param: dict = None,
+    ):
+        super().__init__()
+        cfg = dict(locals())
+        for k in ("self", "__class__"):
+            cfg.pop(k, None)
+        self._register_config(**cfg)
+        bad = []
+        if act_fn != "silu": bad.append("act_fn")
+        if use_linear_projection: bad.append("use_linear_projection")
+        if class_embed_type is not None or num_class_embeds is not None: bad.append("class embedding")
+        if only_cross_attention not in (False, [False] * 4, (False,) * 4): bad.append("only_cross_attention")
+        if resnet_time_scale_shift != "default": bad.append("resnet_time_scale_shift")
+        if global_pool_conditions: bad.append("global_pool_conditions")
+        if use_uncond_map is not None and drop_cond_ratio > 0: bad.append("use_uncond_map")
+        if bad:
+            raise NotImplementedError("BEVControlNetModel (HIP): unsupported config: %s" % bad)
+        n = len(down_block_types)
+        heads = (attention_head_dim,) * n if isinstance(attention_head_dim, int) else tuple(attention_head_dim)
+        c0 = block_out_channels[0]
+        ted = c0 * 4
+
+        # BEV camera (:114-127)
+        self.cam2token = Linear(camera_in_dim, camera_out_dim)
+        if uncond_cam_in_dim:
+            self.uncond_cam = _Embedding1(1, uncond_cam_in_dim[0] * uncond_cam_in_dim[1])
+            self.uncond_cam_num = uncond_cam_in_dim[1]
+        self.drop_cond_ratio, self.drop_cam_num, self.drop_cam_with_box = drop_cond_ratio, drop_cam_num, drop_cam_with_box
+        self.cam_embedder = get_embedder(**(cam_embedder_param or dict(input_dims=3, num_freqs=4)))
+
+        self.conv_in = Conv3x3(in_channels, c0)
+        self.time_proj = Timesteps(c0, flip_sin_to_cos, freq_shift)
+        self.time_embedding = TimestepEmbedding(c0, ted)
+        self.class_embedding = None
+
+        # condition embedder, loaded by dotted path like the reference (:181-193)
+        if map_embedder_cls is None:
+            from .map_embedder import ControlNetConditioningEmbedding as cond_cls
+            emb_param = {"block_out_channels": conditioning_embedding_out_channels or (16, 32, 96, 256)}
+        else:
+            cond_cls = load_module(_own_path(map_embedder_cls))
+            emb_param = map_embedder_param or {}
+        self.controlnet_cond_embedding = cond_cls(conditioning_embedding_channels=c0, **emb_param)
+        self.uncond_map = None
+
+        if bbox_embedder_cls is None:
+            from .bbox_embedder import ContinuousBBoxWithTextEmbedding as box_cls
+            bbox_embedder_param = bbox_embedder_param or dict(
+                n_classes=10, class_token_dim=768, embedder_num_freq=4, proj_dims=[768, 512, 512, 768],
+                mode="all-xyz", minmax_normalize=False, use_text_encoder_init=False)
+        else:
+            box_cls = load_module(_own_path(bbox_embedder_cls))
+        self.bbox_embedder = box_cls(**bbox_embedder_param)
+
+        self.down_blocks = nn.ModuleList([])
+        self.controlnet_down_blocks = nn.ModuleList([Linear(c0, c0, conv=True)])
+        oc = c0
+        for i, t in enumerate(down_block_types):
+            ic, oc = oc, block_out_channels[i]
+            final = i == n - 1
+            if t == "CrossAttnDownBlock2D":
+                self.down_blocks.append(CrossAttnDownBlock2D(ic, oc, ted, layers_per_block, heads[i],
+                                                             cross_attention_dim, not final, norm_num_groups, norm_eps))
+            elif t == "DownBlock2D":
+                self.down_blocks.append(DownBlock2D(ic, oc, ted, layers_per_block, not final, norm_num_groups, norm_eps))
+            else:
+                raise NotImplementedError(t)
+            for _ in range(layers_per_block + (0 if final else 1)):
+                self.controlnet_down_blocks.append(Linear(oc, oc, conv=True))
+        self.controlnet_mid_block = Linear(oc, oc, conv=True)
+        self.mid_block = UNetMidBlock2DCrossAttn(oc, ted, heads[-1], cross_attention_dim, norm_num_groups, norm_eps)
+
+        # created by default, nulled by the caller when unused (:297-306, test_utils.py:123-136)
+        self.adm_proj = _AdmProj(768 + ted, ted)
+        self.txt_con_fusion = txt_con_XFormersAttn()
+        self.txt_con_fusionp = txt_con_XFormersAttn_plus()
+        # behaviour flags the reference sets as plain attributes after construction
+        self.use_cam_in_temb = False
+        self.use_box_adapter = False
+        self.use_txt_con_fusion = False
+        self.use_txt_con_fusionp = False
+        self.use_occ_3d = False
+        self.use_aug_text = False
+
+    # ------------------------------------------------------------------ camera / token helpers --
+    def _embed_camera(self, camera_param):
+        """(b, n, 3, 7) -> (b, n, 189): Fourier-embed each of the 7 column vectors (:308-325)."""
+        bs, n_cam, c_param, emb_num = camera_param.shape
+        assert c_param == 3
+        assert emb_num == self.uncond_cam_num or self.uncond_cam_num is None
+        e = self.cam_embedder(camera_param.permute(0, 1, 3, 2))
+        return e.reshape(bs, n_cam, -1)
+
+    def uncond_cam_param(self, repeat_size: Union[List[int], int] = 1):
+        if isinstance(repeat_size, int):
+            repeat_size = [1, repeat_size]
+        n = int(np.prod(repeat_size))
+        p = self.uncond_cam.weight[0][None].expand(n, -1)
+        return p.reshape(*repeat_size, -1, self.uncond_cam_num)
+
+    def add_cam_states(self, encoder_hidden_states, camera_emb=None):
+        """-> (b, n_cam, len + 1, 768) with the camera token first (:337-361)."""
+        bs = encoder_hidden_states.shape[0]
+        if camera_emb is None:
+            camera_emb = self._embed_camera(self.uncond_cam_param(bs))
+        b, n_cam, k = camera_emb.shape
+        cam = self.cam2token.run(camera_emb.reshape(b * n_cam, k).to(self.dtype).contiguous())
+        cam = cam.reshape(b, n_cam, 1, -1)
+        e = encoder_hidden_states.to(self.dtype)
+        if self.use_aug_text:
+            e = e.reshape(-1, n_cam, *e.shape[1:])
+        else:
+            e = e[:, None].expand(-1, n_cam, -1, -1)
+        return torch.cat([cam, e], dim=2)
+
+    def add_uncond_to_kwargs(self, camera_param, bboxes_3d_data, image, max_len=None, **kwargs):
+        """Builds the CFG batch, uncond half first (:671-769)."""
+        batch_size, n_cam = camera_param.shape[:2]
+        ret = {"camera_param": torch.cat([self.uncond_cam_param([batch_size, n_cam]).to(camera_param), camera_param])}
+
+        def one(data):
+            if data is None:
+                logging.warning("Your 'bboxes_3d_data' should not be None.")
+                if max_len is None:
+                    return None
+                dev = camera_param.device
+                return {"bboxes": torch.zeros([batch_size * 2, n_cam, max_len, 8, 3], device=dev),
+                        "classes": torch.zeros([batch_size * 2, n_cam, max_len], device=dev, dtype=torch.long),
+                        "masks": torch.zeros([batch_size * 2, n_cam, max_len], device=dev, dtype=torch.bool)}
+            out = {}
+            for key in ("bboxes", "classes", "masks"):
+                v = torch.cat([torch.zeros_like(data[key]), data[key]])
+                if max_len is not None:
+                    pad = max_len - v.shape[2]
+                    assert pad >= 0
+                    z = torch.zeros_like(v)[:, :, 1]
+                    v = torch.cat([v, z[:, :, None].expand(-1, -1, pad, *z.shape[2:])], dim=2)
+                out[key] = v
+            return out
+
+        ret["bboxes_3d_data"] = [one(d) for d in bboxes_3d_data] if isinstance(bboxes_3d_data, list) \
+            else one(bboxes_3d_data)
+        ret["image"] = image
+        ret.update(kwargs)
+        return ret
+
+    def prepare(self, cfg, **kwargs):
+        self.bbox_embedder.prepare(cfg, **kwargs)
+
+    # -------------------------------------------------------------------------------- forward --
+    def prepare_condition(self, camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
+                          use_aug_text=False):
+        """Step-invariant half of forward() (:831-896, :967-988).  Returns a dict with
+        `ctx2d` ((b n)*(78+N), 768), `lc`, `cond` ((b n)*h*w, 320) NHWC, `m`, `h`, `w`."""
+        self.use_aug_text = use_aug_text
+        dt = self.dtype
+        if self.config.controlnet_conditioning_channel_order == "bgr":
+            controlnet_cond = torch.flip(controlnet_cond, dims=[1])
+        b, n_cam = camera_param.shape[:2]
+        ctx = self.add_cam_states(encoder_hidden_states, self._embed_camera(camera_param))    # b, n, L+1, 768
+        box = None
+        if bboxes_3d_data is not None:
+            if self.use_box_adapter:
+                raise NotImplementedError("use_box_adapter (SURVEY.md §8f N1)")
+            nb = bboxes_3d_data["bboxes"].shape[1]
+            flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in bboxes_3d_data.items()}
+            box = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"])
+            box = box.reshape(b, nb, *box.shape[1:])
+            if nb != n_cam:
+                assert nb == 1, "either N_cam or 1."
+                box = box.expand(-1, n_cam, -1, -1)
+        m = b * n_cam
+        ctx = ctx.reshape(m, ctx.shape[2], ctx.shape[3])
+        if not self.use_occ_3d:
+            cond, mc, h, w = self.controlnet_cond_embedding.run(controlnet_cond)
+        else:
+            assert self.controlnet_cond_embedding is None
+            cond, mc, h, w = to_nhwc(controlnet_cond.to(dt))
+        assert mc == m, "condition batch %d != b*n_cam %d" % (mc, m)
+        assert not (self.use_txt_con_fusion and self.use_txt_con_fusionp)
+        if self.use_txt_con_fusion or self.use_txt_con_fusionp:
+            sfa = self.txt_con_fusion if self.use_txt_con_fusion else self.txt_con_fusionp
+            txt = ctx[:, 1:].contiguous()                               # without the camera token (:977)
+            cond = sfa.run(cond, m, h * w, txt.reshape(-1, txt.shape[-1]), txt.shape[1])
+        else:
+            assert self.txt_con_fusion is None or not self.use_txt_con_fusion
+        full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1007
+        full = full.contiguous()
+        return {"ctx": full, "ctx2d": full.reshape(-1, full.shape[-1]), "lc": full.shape[1],
+                "cond": cond, "m": m, "h": h, "w": w}
+
+    def forward_nhwc(self, x, m, h, w, t_f32, prep, conditioning_scale=1.0, out=None, accumulate=False):
+        """x: (m*h*w, 8) padded NHWC latents; returns [12 down residuals] + [mid] as NHWC 2-D tensors
+        (each with its (h, w)).  With `out` (same structure) the zero convs write / accumulate in
+        place — the dual-branch sum of pipeline_bev_controlnet.py:421-429 without extra passes."""
+        dt = self.dtype
+        assert not self.use_cam_in_temb, "not available now (:954)"
+        emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
+        temb = self.temb_bank.run(O.silu(emb))
+        ctx2d, lc = prep["ctx2d"], prep["lc"]
+        x = self.conv_in.run(x, m, h, w, res=prep["cond"])              # conv_in + `sample += cond` (:965,:990)
+        skips = [(x, h, w)]
+        for blk in self.down_blocks:
+            x, h, w, s = run_down_block(blk, x, m, h, w, temb, ctx2d, lc)
+            skips += s
+        x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc)
+        outs = []
+        for i, ((s, sh, sw), zc) in enumerate(zip(skips, self.controlnet_down_blocks)):       # :1031-1054
+            dst = out[i][0] if out is not None else None
+            outs.append((zc.run(s, alpha=conditioning_scale, out=dst, accumulate=accumulate), sh, sw))
+        dst = out[-1][0] if out is not None else None
+        outs.append((self.controlnet_mid_block.run(x, alpha=conditioning_scale, out=dst, accumulate=accumulate), h, w))
+        return outs
+
+    def forward(
+        self,
+        sample: torch.Tensor,
+        timestep: Union[torch.Tensor, float, int],
+        camera_param: torch.Tensor,
+        bboxes_3d_data: Dict[str, Any],
+        encoder_hidden_states: torch.Tensor,
+        controlnet_cond: torch.Tensor,
+        encoder_hidden_states_uncond: torch.Tensor = None,
+        conditioning_scale: float = 1.0,
+        class_labels: Optional[torch.Tensor] = None,
+        timestep_cond: Optional[torch.Tensor] = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+        guess_mode: bool = False,
+        return_dict: bool = True,
+        **kwargs,
+    ):
+        use_aug_text = kwargs["use_aug_text"]          # required, as in the reference (:812)
+        if attention_mask is not None or class_labels is not None or timestep_cond is not None or guess_mode:
+            raise NotImplementedError("attention_mask / class_labels / timestep_cond / guess_mode are unused "
+                                      "by the DualDiff sampling path")
+        if not sample.is_cuda:
+            raise RuntimeError("dualdiff_amd runs on the GPU only; got a %s tensor" % sample.device)
+        dt = self.dtype
+        b, n_cam = sample.shape[:2]
+        prep = self.prepare_condition(camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
+                                      use_aug_text)
+        x, m, h, w = to_nhwc(sample.reshape(b * n_cam, *sample.shape[2:]).to(dt))
+        if x.shape[1] != self.conv_in.cin_pad:
+            x = torch.nn.functional.pad(x, (0, self.conv_in.cin_pad - x.shape[1]))
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)], device=sample.device)
+        t = t.to(device=sample.device, dtype=torch.float32).reshape(-1)
+        t = t.repeat_interleave(m // t.numel()) if t.numel() != m else t          # :951-952
+        outs = self.forward_nhwc(x, m, h, w, t.contiguous(), prep, conditioning_scale)
+        down = [as_nchw_view(o, m, oh, ow) for o, oh, ow in outs[:-1]]
+        mo, mh, mw = outs[-1]
+        mid = as_nchw_view(mo, m, mh, mw)
+        ctx = prep["ctx"]
+        if not return_dict:
+            return down, mid, ctx
+        return BEVControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid,
+                                   encoder_hidden_states_with_cam=ctx)
+
+
+def _own_path(dotted):
+    """Configs written for the reference name `magicdrive.networks.*` classes; map them onto this
+    package so an unchanged ControlNet config.json loads."""
+    if dotted.startswith("magicdrive."):
+        return "dualdiff_amd." + dotted[len("magicdrive."):]
+    return dotted

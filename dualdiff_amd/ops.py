@@ -15,6 +15,46 @@ _WS = {}
 _WS_MIN_BYTES = 64 << 20
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py roofline leg).
+
+    When installed (`ops.set_timer(KernelTimer())`) every gemm / conv3x3 / attention launch is
+    bracketed by events recorded on the stream the kernel is launched on; `summary()` groups the
+    launches by kernel symbol and returns count, total time and algorithmic FLOPs."""
+
+    def __init__(self):
+        self.records = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def stop(self, e0, name, flops, nbytes):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream())
+        self.records.append((name, flops, nbytes, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, {"count": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["count"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
 def _dt(t):
     if t.dtype == torch.float16:
         return DD_F16
@@ -50,6 +90,12 @@ def workspace(nbytes, device):
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
+
+
+def _kname(lib, d):
+    full = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
+    name, rest = full.split(" split=")
+    return name if rest.startswith("1 ") else name + " +splitk_reduce"
 
 
 def _rows2d(t):
@@ -97,6 +143,12 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     if need > 0:
         ws = workspace(need, a.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
+    if _TIMER is not None:
+        e0 = _TIMER.start()
+        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
+        _TIMER.stop(e0, _kname(lib, d),
+                    2.0 * rows * n_w * k, 2.0 * (rows * k + n_w * k + rows * n))
+        return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
     return out
 
@@ -145,6 +197,12 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     if need > 0:
         ws = workspace(need, x.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
+    if _TIMER is not None:
+        e0 = _TIMER.start()
+        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
+        _TIMER.stop(e0, _kname(lib, d),
+                    2.0 * rows * cout * 9 * cin, 2.0 * (x.numel() + w.numel() + rows * cout))
+        return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
     return out
 
@@ -208,6 +266,13 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     d.accumulate = int(accumulate)
     d.dtype = _dt(q)
     d.variant = variant
+    if _TIMER is not None:
+        e0 = _TIMER.start()
+        _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
+        _TIMER.stop(e0, "dd_attn_kernel<%s,D%d>" % ("f16" if d.dtype == DD_F16 else "bf16", head_dim),
+                    4.0 * batch * heads * lq * lk * head_dim,
+                    2.0 * heads * head_dim * batch * (2 * lq + 2 * lk))
+        return out
     _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
     return out
 
