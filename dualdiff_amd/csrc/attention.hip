@@ -304,6 +304,7 @@ extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
   p.scale_log2 = d->scale * 1.44269504088896340736f;
   p.kv_map = d->kv_batch_map; p.accumulate = d->accumulate;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   if (d->dtype == DD_F16) return launch_attn_t<_Float16>(d, p, s);
   return launch_attn_t<__bf16>(d, p, s);
 }

@@ -77,6 +77,9 @@ __device__ __forceinline__ float dd_wave_max(float v) {
   return v;
 }
 
+// hipGetLastError() is sticky per thread: a benign earlier error of ANY runtime call (e.g. torch's
+// hipEventQuery -> hipErrorNotReady) would otherwise be reported as our launch failure.
+static inline void dd_clear_error() { (void)hipGetLastError(); }
 static inline int dd_check_launch() {
   return hipGetLastError() == hipSuccess ? DD_OK : DD_ERR_LAUNCH;
 }

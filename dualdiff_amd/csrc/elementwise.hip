@@ -160,6 +160,7 @@ extern "C" int dd_add(const void* a, const void* b, const void* c, void* y, int6
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(a) || !dd_aligned16(b) || !dd_aligned16(y) || (c && !dd_aligned16(c))) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int64_t nvec = n / 8;
   if (dtype == DD_F16)
     hipLaunchKernelGGL(dd_add_kernel<_Float16>, dim3(grid_for(nvec)), dim3(256), 0, s,
@@ -175,6 +176,7 @@ extern "C" int dd_scale(const void* x, void* y, float sc, int64_t n, int32_t dty
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(x) || !dd_aligned16(y)) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int64_t nvec = n / 8;
   if (dtype == DD_F16)
     hipLaunchKernelGGL((dd_unary_kernel<_Float16, 0>), dim3(grid_for(nvec)), dim3(256), 0, s,
@@ -190,6 +192,7 @@ extern "C" int dd_silu(const void* x, void* y, int64_t n, int32_t dtype, dd_stre
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(x) || !dd_aligned16(y)) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int64_t nvec = n / 8;
   if (dtype == DD_F16)
     hipLaunchKernelGGL((dd_unary_kernel<_Float16, 1>), dim3(grid_for(nvec)), dim3(256), 0, s,
@@ -205,6 +208,7 @@ extern "C" int dd_nchw_to_nhwc(const void* x, void* y, int32_t m, int32_t c, int
   if (!x || !y || m <= 0 || c <= 0 || hw <= 0 || c_pad < c) return DD_ERR_BAD_ARG;
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int64_t total = (int64_t)m * hw * c_pad;
   if (dtype == DD_F16)
     hipLaunchKernelGGL(dd_nchw_to_nhwc_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, s,
@@ -220,6 +224,7 @@ extern "C" int dd_nhwc_to_nchw(const void* x, void* y, int32_t m, int32_t c, int
   if (!x || !y || m <= 0 || c <= 0 || hw <= 0 || ldx < c) return DD_ERR_BAD_ARG;
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int64_t total = (int64_t)m * hw * c;
   if (dtype == DD_F16)
     hipLaunchKernelGGL(dd_nhwc_to_nchw_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, s,
@@ -236,6 +241,7 @@ extern "C" int dd_timestep_embedding(const float* t, void* out, int32_t n, int32
   if (!t || !out || n <= 0 || dim <= 0 || (dim & 1)) return DD_ERR_BAD_ARG;
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int total = n * (dim / 2);
   if (dtype == DD_F16)
     hipLaunchKernelGGL(dd_timestep_embedding_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, s,
@@ -254,6 +260,7 @@ extern "C" int dd_conv3x3_small_cout(const void* x, const void* w, const void* b
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(x) || !dd_aligned16(w)) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const int64_t npix = (int64_t)m * h * wd;
   const unsigned blocks = (unsigned)((npix + 3) / 4);
   if (dtype == DD_F16)
@@ -273,6 +280,7 @@ extern "C" int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, voi
   if (!eps || !x || !x_out || !coef || n <= 0) return DD_ERR_BAD_ARG;
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   if (dtype == DD_F16)
     hipLaunchKernelGGL(dd_cfg_ddim_kernel<_Float16>, dim3(grid_for(n)), dim3(256), 0, s,
                        (const _Float16*)eps, (const _Float16*)x, (_Float16*)x_out, (_Float16*)x_dup,

@@ -550,6 +550,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
     p.partial = reinterpret_cast<float*>(d->ws);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   if (d->dtype == DD_F16) return launch_dtype<_Float16>(d, p, pl, s);
   return launch_dtype<__bf16>(d, p, pl, s);
 }

@@ -230,6 +230,7 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
   p.ws = reinterpret_cast<float*>(ws);
   p.nsplit = gn_plan(hw, c, &p.pix_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   dim3 grid(p.nsplit, m);
   if (dtype == DD_F16) {
     hipLaunchKernelGGL(dd_gn_stats_kernel<_Float16>, grid, dim3(GN_THREADS), 0, s, p);
@@ -249,6 +250,7 @@ extern "C" int dd_layernorm(const void* x, const void* gamma, const void* beta, 
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(x) || !dd_aligned16(y) || !dd_aligned16(gamma) || !dd_aligned16(beta)) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
   const unsigned blocks = (unsigned)((rows + 3) / 4);
   if (dtype == DD_F16) {
     hipLaunchKernelGGL(dd_layernorm_kernel<_Float16>, dim3(blocks), dim3(256), 0, s,

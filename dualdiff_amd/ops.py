@@ -49,6 +49,60 @@ class KernelTimer:
 
 _TIMER = None
 
+# ---- run-time tile / split-K selection ---------------------------------------------------------
+# The step touches a finite set of GEMM / conv shapes.  On first (eager, non-captured) use of a
+# shape every tile config x split-K candidate of dd_gemm is timed with HIP events on a scratch
+# output and the fastest is cached; graph capture then records the tuned launches.
+# DD_AUTOTUNE=0 falls back to the built-in heuristic of csrc/gemm.hip.
+import os as _os
+
+_AUTOTUNE = _os.environ.get("DD_AUTOTUNE", "1") != "0"
+_TUNED = {}
+_TILES = (1, 2, 3, 4, 5)
+_SPLITS = (1, 2, 4, 8, 16)
+
+
+def tuned_table():
+    return dict(_TUNED)
+
+
+def _autotune(lib, d, key, out_shape, dtype, device):
+    if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 0, 0
+    hit = _TUNED.get(key)
+    if hit is not None:
+        return hit
+    saved = (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes)
+    scratch = torch.empty(out_shape, dtype=dtype, device=device)
+    d.out, d.ldc, d.accumulate = scratch.data_ptr(), scratch.stride(0), 0
+    kt = (d.k + 63) // 64
+    blocks128 = ((d.rows + 127) // 128) * ((d.n + 127) // 128)
+    best, best_t = (0, 0), float("inf")
+    stream = _stream()
+    for tile in _TILES:
+        for split in _SPLITS:
+            if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):
+                continue
+            d.tile, d.split_k = tile, split
+            need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
+            if need > 0:
+                ws = workspace(need, device)
+                d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+            if lib.dd_gemm(ctypes.byref(d), stream) != 0:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                lib.dd_gemm(ctypes.byref(d), stream)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = (tile, split), t
+    (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
+    _TUNED[key] = best
+    return best
+
 
 def set_timer(t):
     global _TIMER
@@ -139,6 +193,9 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     d.alpha = alpha; d.accumulate = int(accumulate); d.epilogue = epilogue
     d.conv = 0
     d.dtype = _dt(a); d.tile = tile; d.split_k = split_k
+    if tile == 0 and split_k == 0:
+        d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None),
+                                      (rows, n), a.dtype, a.device)
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
         ws = workspace(need, a.device)
@@ -193,6 +250,9 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     d.hin, d.win, d.cin, d.hv, d.wv = hin, win, cin, hv, wv
     d.hout, d.wout, d.stride = hout, wout, stride
     d.dtype = _dt(x); d.tile = tile; d.split_k = split_k
+    if tile == 0 and split_k == 0:
+        d.tile, d.split_k = _autotune(lib, d, ("c", m, hin, win, cin, cout, stride, hv, wv, d.dtype),
+                                      (rows, cout), x.dtype, x.device)
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
         ws = workspace(need, x.device)
