@@ -5,6 +5,11 @@ import of any op fails loudly (RuntimeError) instead of silently running somethi
 """
 import ctypes
 import os
+
+# torch must be imported BEFORE the library is dlopen'ed: PyTorch-ROCm ships its own libamdhip64
+# and the process must end up with ONE HIP runtime (ours resolves to the already-loaded soname);
+# loading ours first gives two runtimes and every launch on a torch stream fails.
+import torch  # noqa: F401
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p)
 
 from . import _build

@@ -40,11 +40,14 @@ __device__ __forceinline__ const T* gn_src(const GnParams& p, int64_t row, int c
                    : reinterpret_cast<const T*>(p.x2) + row * p.c2 + (ch - p.c1);
 }
 
+constexpr int GN_UNROLL = 4;
+
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS)
 void dd_gn_stats_kernel(const GnParams p) {
   // Deterministic (fixed-order) reduction: every thread publishes the partial sums of the (at most
-  // two) groups its 8-channel vector touches; one thread per group then adds them in thread order.
+  // two) groups its 8-channel vector touches; one thread per group then adds, in a fixed order, only
+  // the threads whose vector can overlap that group.
   __shared__ float s_a0[GN_THREADS], s_b0[GN_THREADS], s_a1[GN_THREADS], s_b1[GN_THREADS];
   __shared__ int s_g0[GN_THREADS], s_g1[GN_THREADS];
   const int split = blockIdx.x, inst = blockIdx.y;
@@ -61,7 +64,21 @@ void dd_gn_stats_kernel(const GnParams p) {
       float s[8], ss[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-      for (int px = p0 + mp.pl; px < p1; px += mp.pl_count) {
+      int px = p0 + mp.pl;
+      for (; px + (GN_UNROLL - 1) * mp.pl_count < p1; px += GN_UNROLL * mp.pl_count) {
+        u32x4 v[GN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u)
+          v[u] = dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px + u * mp.pl_count, ch));
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+          float f[8];
+          dd_unpack8<T>(v[u], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+        }
+      }
+      for (; px < p1; px += mp.pl_count) {
         float f[8];
         dd_unpack8<T>(dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px, ch)), f);
 #pragma unroll
@@ -82,9 +99,15 @@ void dd_gn_stats_kernel(const GnParams p) {
     __syncthreads();
     if (threadIdx.x < p.groups) {
       const int g = threadIdx.x;
-      for (int t = 0; t < GN_THREADS; ++t) {
-        if (s_g0[t] == g) { gsum += s_a0[t]; gsq += s_b0[t]; }
-        if (s_g1[t] == g) { gsum += s_a1[t]; gsq += s_b1[t]; }
+      // channel vectors that can overlap group g, clipped to this pass
+      const int lo = max((g * p.cpg) >> 3, cv0);
+      const int hi = min(((g + 1) * p.cpg - 1) >> 3, min(cv0 + GN_THREADS, mp.cv_count) - 1);
+      for (int pl = 0; pl < mp.pl_count; ++pl) {
+        for (int c = lo; c <= hi; ++c) {
+          const int t = mp.cv_count >= GN_THREADS ? (c - cv0) : pl * mp.cv_count + c;
+          if (s_g0[t] == g) { gsum += s_a0[t]; gsq += s_b0[t]; }
+          if (s_g1[t] == g) { gsum += s_a1[t]; gsq += s_b1[t]; }
+        }
       }
     }
     __syncthreads();
@@ -127,17 +150,27 @@ void dd_gn_apply_kernel(const GnParams p) {
       sc[e] = s_rstd[g] * ga[e];
       sh[e] = be[e] - s_mean[g] * sc[e];
     }
-    for (int px = p0 + mp.pl; px < p1; px += mp.pl_count) {
-      const int64_t row = (int64_t)inst * p.hw + px;
+    auto apply_store = [&](u32x4 v, int64_t row) {
       float f[8];
-      dd_unpack8<T>(dd_ld16(gn_src<T>(p, row, ch)), f);
+      dd_unpack8<T>(v, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = f[e] * sc[e] + sh[e];
-        f[e] = p.silu ? dd_silu_f(v) : v;
+        const float y = f[e] * sc[e] + sh[e];
+        f[e] = p.silu ? dd_silu_f(y) : y;
       }
       dd_st16(reinterpret_cast<T*>(p.y) + row * p.c + ch, dd_pack8<T>(f));
+    };
+    int px = p0 + mp.pl;
+    for (; px + (GN_UNROLL - 1) * mp.pl_count < p1; px += GN_UNROLL * mp.pl_count) {
+      u32x4 v[GN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u)
+        v[u] = dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px + u * mp.pl_count, ch));
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) apply_store(v[u], (int64_t)inst * p.hw + px + u * mp.pl_count);
     }
+    for (; px < p1; px += mp.pl_count)
+      apply_store(dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px, ch)), (int64_t)inst * p.hw + px);
   }
 }
 
@@ -194,7 +227,7 @@ int gn_plan(int hw, int c, int* pix_per_split) {
   const int cv = c / 8;
   const int pl = cv >= GN_THREADS ? 1 : GN_THREADS / cv;
   int pps = (hw + GN_MAX_SPLIT - 1) / GN_MAX_SPLIT;
-  const int min_pps = pl * 2;
+  const int min_pps = pl * GN_UNROLL;
   if (pps < min_pps) pps = min_pps;
   if (pps > hw) pps = hw;
   *pix_per_split = pps;

@@ -67,11 +67,11 @@ def tuned_table():
 
 
 def _autotune(lib, d, key, out_shape, dtype, device):
-    if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
-        return 0, 0
     hit = _TUNED.get(key)
     if hit is not None:
         return hit
+    if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 0, 0
     saved = (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes)
     scratch = torch.empty(out_shape, dtype=dtype, device=device)
     d.out, d.ldc, d.accumulate = scratch.data_ptr(), scratch.stride(0), 0
