@@ -55,6 +55,7 @@ SIGNATURES = {
     "dd_gemm": (c_int32, [POINTER(GemmDesc), c_void_p]),
     "dd_gemm_workspace_bytes": (c_int64, [POINTER(GemmDesc)]),
     "dd_gemm_num_tiles": (c_int32, []),
+    "dd_gemm_tile_id": (c_int32, [c_int32]),
     "dd_gemm_kernel_name": (c_char_p, [POINTER(GemmDesc)]),
     "dd_groupnorm_nhwc": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                     c_int32, c_int32, c_int32, c_float, c_int32, c_int32,

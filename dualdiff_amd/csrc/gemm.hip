@@ -84,6 +84,66 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// ---- accumulator tile -> global (shared by both kernel families) ---------------------------
+// acc[tn][tm][reg]: output row = tile row tm*16 + (lane & 15),
+//                   output col = q*(4*TN) + tn*4 + reg  (q = lane >> 4)   [non-GEGLU]
+template <typename T, int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
+                                           int block_n0, int wave_m, int wave_n, int lane) {
+  const int q = lane >> 4;
+  const int c = lane & 15;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = block_m0 + wave_m * (TM * 16) + tm * 16 + c;
+    if (row >= p.rows) continue;
+    if (GEGLU) {
+      constexpr int TH = TN / 2;
+      const int col0 = block_n0 + wave_n * (TH * 16) + q * (4 * TH);
+#pragma unroll
+      for (int g8 = 0; g8 < TH / 2; ++g8) {
+        const int col = col0 + g8 * 8;
+        if (col >= p.n) continue;
+        float h[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          h[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+          g[e] = acc[TH + g8 * 2 + (e >> 2)][tm][e & 3];
+        }
+        if (p.bias) {
+          float b[8];
+          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + col), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] += b[e];
+          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + p.n + col), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] += b[e];
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = h[e] * dd_gelu_erf_f(g[e]);
+        dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
+      }
+    } else {
+      const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
+#pragma unroll
+      for (int g8 = 0; g8 < TN / 2; ++g8) {
+        const int col = col0 + g8 * 8;
+        if (col >= p.n) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+        if (p.partial) {
+          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
+          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          epilogue_store8<T>(p, row, col, v);
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 void dd_gemm_kernel(const GemmParams p) {
@@ -272,61 +332,206 @@ void dd_gemm_kernel(const GemmParams p) {
     buf ^= 1;
   }
 
-  // ---- epilogue -------------------------------------------------------------------------
-  // acc[tn][tm][reg]: output row = tile row tm*16 + (lane & 15),
-  //                   output col = q*(4*TN) + tn*4 + reg  (q = lane >> 4)   [non-GEGLU]
-  const int q = lane >> 4;
-  const int c = lane & 15;
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane);
+}
+
+// =============================================================================================
+// Kernel family 2: LDS-DMA (global_load_lds, 16 B / lane) multi-stage ring.
+//  * no staging registers and no ds_write: tiles land in LDS asynchronously, NSTAGE-1 K-steps ahead;
+//  * the XOR swizzle is applied on the per-lane SOURCE address (the DMA destination is lane-linear);
+//  * padding / tails read a zero page instead of being predicated (DMA cannot write zeros itself);
+//  * counted s_waitcnt vmcnt(N) + raw s_barrier: one barrier per K-step, loads stay in flight
+//    across it.
+// =============================================================================================
+__device__ __attribute__((aligned(256))) unsigned char dd_zero_page[256];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
+void dd_gemm2_kernel(const GemmParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 16;
+  constexpr int BN = WAVES_N * TN * 16;
+  constexpr int BN_OUT = GEGLU ? BN / 2 : BN;
+  constexpr int XI = BM / 8 / NW;                 // DMA wave-instructions (8 rows x 128 B) per wave
+  constexpr int WI = BN / 8 / NW;
+  constexpr int LPS = XI + WI;                    // DMA instructions per thread per stage
+  constexpr int STAGE = (BM + BN) * BK;           // elements per ring slot
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
+  static_assert(NW % 2 == 0, "swizzle must not depend on the instruction index");
+  static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "NSTAGE");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* ring = reinterpret_cast<T*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tile_m = tile / p.tiles_n;
+  const int tile_n = tile % p.tiles_n;
+  const int block_m0 = tile_m * BM;
+  const int block_n0 = tile_n * BN_OUT;
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.k, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // DMA mapping: instruction j of this wave fills tile rows (j*NW + wave)*8 .. +7; lane l writes
+  // row (l >> 3), chunk position (l & 7).  Logical chunk = position ^ ((row >> 1) & 7), which for an
+  // even number of waves does not depend on j.
+  const int lrow = lane >> 3;
+  const int lc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const T* zero = reinterpret_cast<const T*>(dd_zero_page);
+
+  int xm[XI], xiy[XI], xix[XI];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int row = block_m0 + wave_m * (TM * 16) + tm * 16 + c;
-    if (row >= p.rows) continue;
-    if (GEGLU) {
-      constexpr int TH = TN / 2;
-      const int col0 = block_n0 + wave_n * (TH * 16) + q * (4 * TH);
-#pragma unroll
-      for (int g8 = 0; g8 < TH / 2; ++g8) {
-        const int col = col0 + g8 * 8;
-        if (col >= p.n) continue;
-        float h[8], g[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          h[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
-          g[e] = acc[TH + g8 * 2 + (e >> 2)][tm][e & 3];
-        }
-        if (p.bias) {
-          float b[8];
-          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + col), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) h[e] += b[e];
-          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + p.n + col), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) g[e] += b[e];
-        }
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = h[e] * dd_gelu_erf_f(g[e]);
-        dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
+  for (int j = 0; j < XI; ++j) {
+    const int r = block_m0 + (j * NW + wave) * 8 + lrow;
+    if (r < p.rows) {
+      if (CONV) {
+        const int hw = p.hout * p.wout;
+        const int inst = r / hw;
+        const int rem = r - inst * hw;
+        const int oy = rem / p.wout;
+        const int ox = rem - oy * p.wout;
+        xm[j] = inst;
+        xiy[j] = oy * p.stride - 1;
+        xix[j] = ox * p.stride - 1;
+      } else {
+        xm[j] = r; xiy[j] = 0; xix[j] = 0;
       }
     } else {
-      const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
-#pragma unroll
-      for (int g8 = 0; g8 < TN / 2; ++g8) {
-        const int col = col0 + g8 * 8;
-        if (col >= p.n) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
-        if (p.partial) {
-          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
-          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-          epilogue_store8<T>(p, row, col, v);
-        }
-      }
+      xm[j] = -1; xiy[j] = 0; xix[j] = 0;
     }
   }
+  int64_t wofs[WI];
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int R = (j * NW + wave) * 8 + lrow;
+    const int wv = R / (TN * 16);
+    const int rho = R % (TN * 16);
+    const int tn = rho >> 4, r = rho & 15;
+    int n_glob;
+    if (GEGLU) {
+      constexpr int TH = TN / 2;
+      const int t = tn % TH;
+      const int loc = wv * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
+      const int col = block_n0 + loc;
+      n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
+    } else {
+      const int loc = wv * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
+      const int col = block_n0 + loc;
+      n_glob = (col < p.n) ? col : -1;
+    }
+    wofs[j] = (n_glob >= 0) ? (int64_t)n_glob * p.k : -1;
+  }
+
+  // Exactly ONE DMA instruction per (operand, j) and stage — the counted vmcnt waits below rely on
+  // it — so the real / zero-page source is selected arithmetically, never by a branch.
+  auto pick = [&](const T* real, bool valid) -> const T* {
+    const uintptr_t z = reinterpret_cast<uintptr_t>(zero);
+    const uintptr_t m = valid ? ~(uintptr_t)0 : (uintptr_t)0;
+    return reinterpret_cast<const T*>(z + ((reinterpret_cast<uintptr_t>(real) - z) & m));
+  };
+  auto issue = [&](int kt, int slot) {
+    const int k = kbeg + kt * BK + lc * 8;
+    const bool kok = k < kend;
+    T* xs = ring + slot * STAGE;
+    T* ws = xs + BM * BK;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      const int64_t wo = wofs[j] < 0 ? 0 : wofs[j];
+      glds16(pick(reinterpret_cast<const T*>(p.w) + wo + k, kok && wofs[j] >= 0), ws + (j * NW + wave) * 8 * BK);
+    }
+    if (CONV) {
+      const int tap = k / p.cin;
+      const int ci = k - tap * p.cin;
+      const int ky = tap / 3;
+      const int kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < XI; ++j) {
+        int iy = xiy[j] + ky, ix = xix[j] + kx;
+        const bool valid = kok && xm[j] >= 0 && iy >= 0 && iy < p.hv && ix >= 0 && ix < p.wv;
+        iy = min(max(iy, 0), p.hv - 1);
+        ix = min(max(ix, 0), p.wv - 1);
+        if (p.upsample) {                    // wave-uniform
+          iy = min((int)floorf(iy * p.scale_h), p.hin - 1);
+          ix = min((int)floorf(ix * p.scale_w), p.win - 1);
+        }
+        const int64_t off = (((int64_t)max(xm[j], 0) * p.hin + iy) * p.win + ix) * p.cin + ci;
+        glds16(pick(reinterpret_cast<const T*>(p.a) + off, valid), xs + (j * NW + wave) * 8 * BK);
+      }
+    } else {
+      const bool second = k >= p.k1;
+      const T* base = second ? reinterpret_cast<const T*>(p.a2) : reinterpret_cast<const T*>(p.a);
+      const int64_t ld = second ? p.lda2 : p.lda;
+      const int kk = second ? k - p.k1 : k;
+#pragma unroll
+      for (int j = 0; j < XI; ++j)
+        glds16(pick(base + (int64_t)max(xm[j], 0) * ld + kk, kok && xm[j] >= 0), xs + (j * NW + wave) * 8 * BK);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fswz = (lane >> 1) & 7;
+  const int fchunk = lane >> 4;
+
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nk) issue(s0, s0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
+    if (NSTAGE == 2) {
+      wait_vmcnt<0>();
+    } else {
+      const int ahead = min(nk - 1 - kt, NSTAGE - 2);
+      if (ahead == 0) wait_vmcnt<0>();
+      else if (ahead == 1) wait_vmcnt<LPS>();
+      else wait_vmcnt<2 * LPS>();
+    }
+    __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    const int slot = kt % NSTAGE;
+    const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
+    const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
+      V8 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[i], xf[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane);
 }
 
 // split-K: sum the fp32 partial slabs and run the fused epilogue.
@@ -352,13 +557,24 @@ void dd_splitk_reduce_kernel(const GemmParams p, int nsplit) {
 }
 
 // ---- host side --------------------------------------------------------------------------
-struct TileCfg { int id, wm, wn, tm, tn; const char* name; };
+// stages == 0: register-staged family (dd_gemm_kernel); stages >= 2: LDS-DMA ring (dd_gemm2_kernel)
+struct TileCfg { int id, wm, wn, tm, tn, stages; const char* name; };
 constexpr TileCfg kTiles[] = {
-    {1, 2, 2, 4, 4, "128x128"},
-    {2, 2, 2, 4, 2, "128x64"},
-    {3, 2, 2, 2, 4, "64x128"},
-    {4, 2, 2, 2, 2, "64x64"},
-    {5, 4, 2, 4, 4, "256x128"},
+    {1, 2, 2, 4, 4, 0, "128x128"},
+    {2, 2, 2, 4, 2, 0, "128x64"},
+    {3, 2, 2, 2, 4, 0, "64x128"},
+    {4, 2, 2, 2, 2, 0, "64x64"},
+    {5, 4, 2, 4, 4, 0, "256x128"},
+    {11, 2, 2, 4, 4, 2, "128x128/dma2"},
+    {12, 2, 2, 4, 4, 3, "128x128/dma3"},
+    {13, 2, 2, 4, 2, 3, "128x64/dma3"},
+    {14, 2, 2, 2, 4, 3, "64x128/dma3"},
+    {15, 2, 2, 2, 2, 3, "64x64/dma3"},
+    {16, 4, 2, 4, 4, 2, "256x128/dma2"},
+    {17, 2, 2, 4, 2, 2, "128x64/dma2"},
+    {18, 2, 2, 2, 2, 2, "64x64/dma2"},
+    {19, 2, 2, 2, 2, 4, "64x64/dma4"},
+    {20, 4, 2, 4, 4, 3, "256x128/dma3"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -434,9 +650,35 @@ int launch_cfg(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
+int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
+  auto kern = dd_gemm2_kernel<T, WM, WN, TM, TN, NSTAGE, CONV, GEGLU>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
+  return dd_check_launch();
+}
+
 template <typename T, bool CONV, bool GEGLU>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
   switch (kTiles[pl.tile_idx].id) {
+    case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
+    case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
+    case 14: return launch_cfg2<T, 2, 2, 2, 4, 3, CONV, GEGLU>(p, pl, s);
+    case 16: return launch_cfg2<T, 4, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
+    case 20: return launch_cfg2<T, 4, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
+    case 13: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 3, CONV, false>(p, pl, s); break;
+    case 15: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 3, CONV, false>(p, pl, s); break;
+    case 17: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 2, CONV, false>(p, pl, s); break;
+    case 18: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 2, CONV, false>(p, pl, s); break;
+    case 19: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 4, CONV, false>(p, pl, s); break;
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
@@ -502,6 +744,7 @@ thread_local char g_kname[160];
 }  // namespace
 
 extern "C" int dd_gemm_num_tiles(void) { return kNumTiles; }
+extern "C" int dd_gemm_tile_id(int index) { return (index >= 0 && index < kNumTiles) ? kTiles[index].id : -1; }
 
 extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
   if (validate(d) != DD_OK) return 0;
@@ -515,8 +758,10 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   const Plan pl = make_plan(d);
   const TileCfg& t = kTiles[pl.tile_idx];
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
-  snprintf(g_kname, sizeof(g_kname), "dd_gemm_kernel<%s, %d, %d, %d, %d, %s, %s> split=%d grid=%dx%d tile=%s",
-           d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn,
+  char stage[16] = "";
+  if (t.stages) snprintf(stage, sizeof(stage), " %d,", t.stages);
+  snprintf(g_kname, sizeof(g_kname), "dd_gemm%s_kernel<%s, %d, %d, %d, %d,%s %s, %s> split=%d grid=%dx%d tile=%s",
+           t.stages ? "2" : "", d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, stage,
            d->conv ? "true" : "false", d->epilogue == DD_EPI_GEGLU ? "true" : "false",
            pl.split, pl.tiles_m, pl.tiles_n, t.name);
   return g_kname;

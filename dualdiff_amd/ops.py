@@ -58,7 +58,7 @@ import os as _os
 
 _AUTOTUNE = _os.environ.get("DD_AUTOTUNE", "1") != "0"
 _TUNED = {}
-_TILES = (1, 2, 3, 4, 5)
+_TILES = None           # filled from the library (dd_gemm_tile_id) on first use
 _SPLITS = (1, 2, 4, 8, 16)
 
 
@@ -79,6 +79,9 @@ def _autotune(lib, d, key, out_shape, dtype, device):
     blocks128 = ((d.rows + 127) // 128) * ((d.n + 127) // 128)
     best, best_t = (0, 0), float("inf")
     stream = _stream()
+    global _TILES
+    if _TILES is None:
+        _TILES = tuple(lib.dd_gemm_tile_id(i) for i in range(lib.dd_gemm_num_tiles()))
     for tile in _TILES:
         for split in _SPLITS:
             if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):

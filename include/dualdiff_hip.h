@@ -112,6 +112,8 @@ int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
 /* Workspace bytes dd_gemm needs for this descriptor (0 when split-K is off). */
 int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d);
 int dd_gemm_num_tiles(void);
+/* id of the index-th tile configuration (for tuners); -1 when out of range. */
+int dd_gemm_tile_id(int index);
 /* Name of the kernel symbol dd_gemm would launch for `d` (for profile matching). */
 const char* dd_gemm_kernel_name(const dd_gemm_desc* d);
 

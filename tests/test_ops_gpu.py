@@ -49,8 +49,12 @@ def test_gemm_identity_asymmetric(ops):
     check(y, w.float().cpu().t(), torch.float16, "gemm A=I")
 
 
+ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+DMA_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", ALL_TILES)
 @pytest.mark.parametrize("rows,n,k", [(256, 256, 256), (200, 320, 320), (77, 72, 200), (1400, 320, 2880)])
 def test_gemm_tiles(ops, dtype, tile, rows, n, k):
     a = rnd((rows, k), dtype, 1)
@@ -132,6 +136,52 @@ def test_conv3x3(ops, dtype, case):
     y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, hin, win, stride=stride, up_size=up)
     ref = L.conv3x3_ref(x, w, b, m, hin, win, stride=stride, up_size=up)
     check(y, ref, dtype, "conv %s" % (case,))
+
+
+@pytest.mark.parametrize("tile", DMA_TILES)
+@pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[4], CONV_CASES[7], CONV_CASES[9], CONV_CASES[11]],
+                         ids=lambda c: str(c))
+def test_conv3x3_dma_tiles(ops, tile, case):
+    """LDS-DMA kernel family on the awkward cases: stride 2, folded upsample, wide Cin, padded Cin=8,
+    K tail (Cin=96 -> K=864), for every tile / stage configuration, incl. split-K."""
+    dtype = torch.float16
+    m, hin, win, cin, cout, stride, up = case
+    x = rnd((m * hin * win, cin), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    ref = L.conv3x3_ref(x, w, b, m, hin, win, stride=stride, up_size=up)
+    for split in (1, 3):
+        if split > 1 and 9 * cin < 64 * 4 * split:
+            continue
+        y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, hin, win, stride=stride, up_size=up, tile=tile, split_k=split)
+        check(y, ref, dtype, "conv dma tile%d split%d %s" % (tile, split, case))
+
+
+@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20])
+def test_gemm_geglu_dma_tiles(ops, tile):
+    dtype = torch.bfloat16
+    rows, c = 700, 640
+    a = rnd((rows, c), dtype, 1)
+    w = rnd((8 * c, c), dtype, 2, 0.05)
+    b = rnd((8 * c,), dtype, 3)
+    y = ops.gemm(a, w, b, epilogue=ops.DD_EPI_GEGLU, tile=tile)
+    check(y, L.linear_ref(a, w, b, geglu=True), dtype, "geglu dma tile%d" % tile, 2.0)
+
+
+@pytest.mark.parametrize("tile", DMA_TILES)
+def test_gemm_concat_dma_tiles(ops, tile):
+    """Two-source A operand (up-path shortcut on [h, skip]) + full epilogue on the DMA family."""
+    dtype = torch.float16
+    rows, n, k = 12 * 91, 640, 1280
+    a = rnd((rows, 768), dtype, 1)
+    a2 = rnd((rows, k - 768), dtype, 11)
+    w = rnd((n, k), dtype, 2, 0.03)
+    b = rnd((n,), dtype, 3)
+    res = rnd((rows, n), dtype, 4)
+    rv = rnd((12, n), dtype, 5)
+    y = ops.gemm(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5, tile=tile)
+    ref = L.linear_ref(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5)
+    check(y, ref, dtype, "gemm concat dma tile%d" % tile)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

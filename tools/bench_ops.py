@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O  # noqa: E402
 
 M = 12
+TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
 LEVELS = [(28, 50, 320), (14, 25, 640), (7, 13, 1280), (4, 7, 1280)]
 
 
@@ -67,7 +68,7 @@ def main():
         a, wt, b = r(rows, k), r(n, k, s=0.05), r(n)
         res = r(rows, n)
         best = None
-        for tile in [1, 2, 3, 4, 5]:
+        for tile in TILES:
             for split in ([1] if rows > 2000 else [1, 2, 4, 8]):
                 try:
                     t = timeit(lambda: O.gemm(a, wt, b, res=res, tile=tile, split_k=split))
@@ -86,7 +87,7 @@ def main():
     for (h, w, c) in LEVELS[:3]:
         rows = M * h * w
         a, wt, b = r(rows, c), r(8 * c, c, s=0.05), r(8 * c)
-        for tile in [1, 3, 5]:
+        for tile in [1, 3, 5, 11, 12, 14, 16, 20]:
             t = timeit(lambda: O.gemm(a, wt, b, epilogue=O.DD_EPI_GEGLU, tile=tile))
             emit({"op": "geglu", "rows": rows, "n": 4 * c, "k": c, "tile": tile, "us": t * 1e6,
                   "tflops": 2.0 * rows * 8 * c * c / t / 1e12})
@@ -107,7 +108,7 @@ def main():
         rows = M * ho * wo
         flops = 2.0 * rows * cout * 9 * cin
         best = None
-        for tile in [1, 2, 3, 4, 5]:
+        for tile in TILES:
             for split in ([1] if rows > 4000 else [1, 2, 4, 8, 16]):
                 try:
                     t = timeit(lambda: O.conv3x3(x, wt, b, M, h, w, stride=stride, up_size=up,
