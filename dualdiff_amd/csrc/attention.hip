@@ -19,6 +19,8 @@
 
 namespace {
 
+constexpr float RESCALE_THR = 5.0f;    // log2 units: probabilities stay <= 32
+
 struct AttnParams {
   const void* q; const void* k; const void* v; void* o;
   int64_t ldq, ldk, ldv, ldo;
@@ -29,9 +31,8 @@ struct AttnParams {
   int accumulate;
 };
 
-constexpr int KV_TILE = 64;
 
-template <typename T, int D, int QT, bool TR>
+template <typename T, int D, int QT, bool TR, int KV_TILE>
 __global__ __launch_bounds__(256)
 void dd_attn_kernel(const AttnParams p) {
   using V8 = typename dd_vec<T>::v8;
@@ -44,6 +45,10 @@ void dd_attn_kernel(const AttnParams p) {
   constexpr int KCH = DQ / 8;                  // 16-B chunks per K row in LDS
   constexpr int VCH = DVT * 2;                 // 16-B chunks per V row in LDS
   constexpr int DCH = D / 8;                   // valid chunks per global row
+  // When the PV tile has spare columns (d = 40 -> 48) column D of the V tile holds 1.0, so the MFMA
+  // accumulates the softmax denominator (sum of the *rounded* probabilities, consistent with the
+  // numerator) for free and the VALU row-sum disappears.
+  constexpr bool ONES = (D % 16) != 0;
   constexpr int K_PER_THR = (KV_TILE * KCH + 255) / 256;
   constexpr int V_PER_THR = (KV_TILE * VCH + 255) / 256;
 
@@ -91,6 +96,10 @@ void dd_attn_kernel(const AttnParams p) {
   for (int j = 0; j < QT; ++j) { m_run[j] = -1e30f; l_run[j] = 0.f; }
 
   u32x4 kreg[K_PER_THR], vreg[V_PER_THR];
+  const T one_t = (T)1.0f;
+  unsigned short one_u16;
+  __builtin_memcpy(&one_u16, &one_t, 2);
+  const unsigned one_bits = one_u16;            // element 0 of the 16-B chunk = 1.0, rest 0
 
   auto load_kv = [&](int tile0) {
 #pragma unroll
@@ -109,6 +118,7 @@ void dd_attn_kernel(const AttnParams p) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (idx < KV_TILE * VCH && ch < DCH && tile0 + row < p.lk)
         v = dd_ld16(vbase + (int64_t)(tile0 + row) * p.ldv + ch * 8);
+      if (ONES && idx < KV_TILE * VCH && ch == DCH) v[0] = one_bits;
       vreg[i] = v;
     }
   };
@@ -138,7 +148,7 @@ void dd_attn_kernel(const AttnParams p) {
     if (it + 1 < ntiles) load_kv(tile0 + KV_TILE);   // prefetch under the MFMAs below
 
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
+    for (int cc = 0; cc < KV_TILE / 32; ++cc) {
       const int key0 = tile0 + cc * 32;
       if (key0 >= p.lk) break;                        // uniform
       // ---- S^T = K Q^T for 32 keys ------------------------------------------------------
@@ -159,7 +169,7 @@ void dd_attn_kernel(const AttnParams p) {
           for (int j = 0; j < QT; ++j) sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], sacc[t][j]);
       }
       // ---- online softmax; lane holds keys key0 + t*16 + g*4 + r for query column c -------
-      const bool tail = key0 + 32 > p.lk;             // uniform
+      const bool tail = key0 + 32 > p.lk;             // uniform; only the last chunk is masked
       V8 pf[QT];
 #pragma unroll
       for (int j = 0; j < QT; ++j) {
@@ -167,33 +177,45 @@ void dd_attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = sacc[t][j][r] * p.scale_log2;
-            if (tail && key0 + t * 16 + g * 4 + r >= p.lk) v = -INFINITY;
-            s[t * 4 + r] = v;
-          }
+          for (int r = 0; r < 4; ++r) s[t * 4 + r] = sacc[t][j][r];
+        if (tail) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + t * 16 + g * 4 + r >= p.lk) s[t * 4 + r] = -INFINITY;
+        }
+        // max on the raw scores (scale > 0), one multiply for the row, scale folded into the fma
         float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
                          fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[j], mx);
-        const float alpha = exp2f(m_run[j] - m_new);
-        m_run[j] = m_new;
+        // Deferred rescale: the running max (and the O / l accumulators) are only moved when some
+        // row's max grew by more than 2^RESCALE_THR; until then probabilities are taken against the
+        // old max and may reach 2^RESCALE_THR — exact in floating point up to the usual rounding.
+        const float m_cand = mx * p.scale_log2;
+        if (__any(m_cand - m_run[j] > RESCALE_THR)) {   // wave-uniform, rare after the first tiles
+          const float m_new = fmaxf(m_run[j], m_cand);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+          m_run[j] = m_new;
+          if (!ONES) l_run[j] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DVT; ++dt) {
+            oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
+            oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
+          }
+        }
+        const float m_use = m_run[j];
         float ls = 0.f;
         V8 pv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float pe = exp2f(s[e] - m_new);
-          ls += pe;
+          const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], p.scale_log2, -m_use));
+          if (!ONES) ls += pe;
           pv[e] = (T)pe;
         }
         pf[j] = pv;
-        l_run[j] = l_run[j] * alpha + ls;
-#pragma unroll
-        for (int dt = 0; dt < DVT; ++dt) {
-          oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
-          oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
-        }
+        if (!ONES) l_run[j] += ls;
       }
       // ---- O^T += V^T P^T -----------------------------------------------------------------
 #pragma unroll
@@ -225,9 +247,14 @@ void dd_attn_kernel(const AttnParams p) {
   T* obase = reinterpret_cast<T*>(p.o) + (int64_t)b * p.obs + h * D;
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
-    float l = l_run[j];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (ONES) {       // denominator = accumulator row d == D, held by lane group (D%16)/4, register D%4
+      l = __shfl(oacc[DVT - 1][j][D % 4], ((D % 16) / 4) * 16 + c, 64);
+    } else {
+      l = l_run[j];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     const int qrow = q0 + j * 16 + c;
     if (qrow >= p.lq) continue;
@@ -251,26 +278,30 @@ void dd_attn_kernel(const AttnParams p) {
   }
 }
 
-template <typename T, int D, int QT, bool TR>
+template <typename T, int D, int QT, bool TR, int KV_TILE>
 int launch_attn(const AttnParams& p, hipStream_t s) {
   constexpr int DQ = (D + 31) / 32 * 32;
   constexpr int DVT = (D + 15) / 16;
   constexpr size_t smem = (size_t)KV_TILE * ((DQ + 8) + (DVT * 16 + 8)) * sizeof(T);
   const int qblk = 4 * QT * 16;
   dim3 grid((p.lq + qblk - 1) / qblk, p.batch * p.heads);
-  hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR>), grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR, KV_TILE>), grid, dim3(256), smem, s, p);
   return dd_check_launch();
 }
 
 template <typename T, int D>
 int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
-  // 32 query rows per wave when the sequence is long enough to fill the chip, else 16
+  // 32 query rows per wave when the sequence is long enough to fill the chip, else 16;
+  // 128-key tiles (half the barriers) for long key sequences at the small head dims
   const long blocks128 = (long)((p.lq + 127) / 128) * p.batch * p.heads;
   const bool qt2 = p.lq >= 256 && blocks128 >= 512;
   if (variant == 1) {
-    return qt2 ? launch_attn<T, D, 2, false>(p, s) : launch_attn<T, D, 1, false>(p, s);
+    return qt2 ? launch_attn<T, D, 2, false, 64>(p, s) : launch_attn<T, D, 1, false, 64>(p, s);
   }
-  return qt2 ? launch_attn<T, D, 2, true>(p, s) : launch_attn<T, D, 1, true>(p, s);
+  if constexpr (D <= 80) {
+    if (p.lk >= 512) return qt2 ? launch_attn<T, D, 2, true, 128>(p, s) : launch_attn<T, D, 1, true, 128>(p, s);
+  }
+  return qt2 ? launch_attn<T, D, 2, true, 64>(p, s) : launch_attn<T, D, 1, true, 64>(p, s);
 }
 
 template <typename T>
