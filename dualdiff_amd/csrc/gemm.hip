@@ -35,6 +35,7 @@ struct GemmParams {
   int k_per_split;
   float* partial;
   int tiles_m, tiles_n;
+  int fast;            // 64-aligned K structure + 32-bit element offsets: cheap DMA address path
 };
 
 // --- epilogue on 8 consecutive output channels of one row --------------------------------
@@ -375,7 +376,7 @@ void dd_gemm2_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform -> SALU address math
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
 
@@ -442,12 +443,12 @@ void dd_gemm2_kernel(const GemmParams p) {
 
   // Exactly ONE DMA instruction per (operand, j) and stage — the counted vmcnt waits below rely on
   // it — so the real / zero-page source is selected arithmetically, never by a branch.
-  auto pick = [&](const T* real, bool valid) -> const T* {
+  auto pick = [&](const T* real, bool valid) __attribute__((always_inline)) -> const T* {
     const uintptr_t z = reinterpret_cast<uintptr_t>(zero);
     const uintptr_t m = valid ? ~(uintptr_t)0 : (uintptr_t)0;
     return reinterpret_cast<const T*>(z + ((reinterpret_cast<uintptr_t>(real) - z) & m));
   };
-  auto issue = [&](int kt, int slot) {
+  auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
     const int k = kbeg + kt * BK + lc * 8;
     const bool kok = k < kend;
     T* xs = ring + slot * STAGE;
@@ -486,6 +487,113 @@ void dd_gemm2_kernel(const GemmParams p) {
     }
   };
 
+  // ---- fast address path (p.fast): K is a multiple of 64 so a K-step never straddles a conv tap or
+  // the a/a2 seam, and all element offsets fit 32 bits.  Per DMA instruction: a few VALU ops on
+  // per-row tables built once, instead of 64-bit index arithmetic with divisions.
+  const uintptr_t zaddr = reinterpret_cast<uintptr_t>(zero);
+  uint32_t wrow[WI], wmask[WI];                 // weight row offset (elements), all-ones if valid
+  uint32_t xrow[XI], xrow2[XI], xmask[XI];      // dense: row offsets into a / a2
+  uint32_t syo[XI][3], sxo[XI][3], xbits[XI];   // conv: source row / column offsets per tap, 9-bit validity
+  if (p.fast) {
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      wmask[j] = wofs[j] >= 0 ? 0xFFFFFFFFu : 0u;
+      wrow[j] = wofs[j] >= 0 ? (uint32_t)wofs[j] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const bool rv = xm[j] >= 0;
+      xmask[j] = rv ? 0xFFFFFFFFu : 0u;
+      if (CONV) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int iy = xiy[j] + t, ix = xix[j] + t;
+          const bool vy = iy >= 0 && iy < p.hv, vx = ix >= 0 && ix < p.wv;
+          int sy = min(max(iy, 0), p.hv - 1), sx = min(max(ix, 0), p.wv - 1);
+          if (p.upsample) {
+            sy = min((int)floorf(sy * p.scale_h), p.hin - 1);
+            sx = min((int)floorf(sx * p.scale_w), p.win - 1);
+          }
+          syo[j][t] = (uint32_t)((max(xm[j], 0) * p.hin + sy) * p.win) * (uint32_t)p.cin;
+          sxo[j][t] = (uint32_t)(sx * p.cin);
+          if (vy) bits |= 1u << t;
+          if (vx) bits |= 8u << t;
+        }
+        // bit (ky*3+kx) of xbits: tap valid
+        uint32_t m9 = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if (rv && ((bits >> (t / 3)) & 1u) && ((bits >> (3 + t % 3)) & 1u)) m9 |= 1u << t;
+        xbits[j] = m9;
+        // no upsample: tap (ky,kx) reads pixel (oy0+ky, ox0+kx) -> one per-row base + a scalar tap offset
+        xrow[j] = (uint32_t)(((max(xm[j], 0) * p.hin + xiy[j]) * p.win + xix[j]) * p.cin);
+        xrow2[j] = 0;
+      } else {
+        xrow[j] = rv ? (uint32_t)(xm[j] * (int)p.lda) : 0u;
+        xrow2[j] = rv ? (uint32_t)(xm[j] * (int)p.lda2) : 0u;
+        xbits[j] = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { syo[j][t] = 0; sxo[j][t] = 0; }
+      }
+    }
+  }
+  // src = valid ? base + 2*off : zero page, branch-free (exactly one DMA instruction per call)
+  auto src_of = [&](uintptr_t base, uint32_t off_elems, uint32_t mask) __attribute__((always_inline)) -> const void* {
+    const uintptr_t real = base + ((uintptr_t)off_elems << 1);
+    const uintptr_t m = (uintptr_t)(int64_t)(int32_t)mask;
+    return reinterpret_cast<const void*>(zaddr + ((real - zaddr) & m));
+  };
+  auto issue_fast = [&](int kt, int slot) __attribute__((always_inline)) {
+    const int k0 = kbeg + kt * BK;                    // scalar
+    const uint32_t kl = (uint32_t)(k0 + lc * 8);
+    T* xs = ring + slot * STAGE;
+    T* ws = xs + BM * BK;
+    const uintptr_t wb = reinterpret_cast<uintptr_t>(p.w);
+#pragma unroll
+    for (int j = 0; j < WI; ++j) glds16(src_of(wb, wrow[j] + kl, wmask[j]), ws + (j * NW + wave) * 8 * BK);
+    if (CONV) {
+      const int tap = k0 / p.cin;                     // scalar: 64 | cin
+      const int ci0 = k0 - tap * p.cin;
+      const int ky = tap / 3;
+      const int kx = tap - ky * 3;
+      const uint32_t cl = (uint32_t)(ci0 + lc * 8);
+      const uintptr_t ab = reinterpret_cast<uintptr_t>(p.a);
+      if (p.upsample) {                               // scalar branch; both arms issue XI DMAs
+        // table select by mask arithmetic (a select of array elements would force the tables to scratch)
+        const uint32_t y0 = 0u - (uint32_t)(ky == 0), y1 = 0u - (uint32_t)(ky == 1), y2 = 0u - (uint32_t)(ky == 2);
+        const uint32_t x0 = 0u - (uint32_t)(kx == 0), x1 = 0u - (uint32_t)(kx == 1), x2 = 0u - (uint32_t)(kx == 2);
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+          const uint32_t oy = (syo[j][0] & y0) | (syo[j][1] & y1) | (syo[j][2] & y2);
+          const uint32_t ox = (sxo[j][0] & x0) | (sxo[j][1] & x1) | (sxo[j][2] & x2);
+          const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
+          glds16(src_of(ab, oy + ox + cl, m), xs + (j * NW + wave) * 8 * BK);
+        }
+      } else {
+        const uint32_t toff = (uint32_t)((ky * p.win + kx) * p.cin) + cl;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+          const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
+          glds16(src_of(ab, xrow[j] + toff, m), xs + (j * NW + wave) * 8 * BK);
+        }
+      }
+    } else if (k0 >= p.k1) {                          // scalar: 64 | k1
+      const uintptr_t ab = reinterpret_cast<uintptr_t>(p.a2);
+      const uint32_t kk = kl - (uint32_t)p.k1;
+#pragma unroll
+      for (int j = 0; j < XI; ++j) glds16(src_of(ab, xrow2[j] + kk, xmask[j]), xs + (j * NW + wave) * 8 * BK);
+    } else {
+      const uintptr_t ab = reinterpret_cast<uintptr_t>(p.a);
+#pragma unroll
+      for (int j = 0; j < XI; ++j) glds16(src_of(ab, xrow[j] + kl, xmask[j]), xs + (j * NW + wave) * 8 * BK);
+    }
+  };
+  auto issue_any = [&](int kt, int slot) __attribute__((always_inline)) {
+    if (p.fast) issue_fast(kt, slot);
+    else issue(kt, slot);
+  };
+
   f32x4 acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -498,7 +606,7 @@ void dd_gemm2_kernel(const GemmParams p) {
 
 #pragma unroll
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nk) issue(s0, s0);
+    if (s0 < nk) issue_any(s0, s0);
 
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
@@ -511,7 +619,7 @@ void dd_gemm2_kernel(const GemmParams p) {
       else wait_vmcnt<2 * LPS>();
     }
     __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
-    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    if (kt + NSTAGE - 1 < nk) issue_any(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
     const int slot = kt % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
     const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
@@ -788,6 +896,18 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.scale_w = d->conv ? (float)d->win / (float)d->wv : 1.f;
   p.k_per_split = pl.k_per_split;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  {
+    const int64_t lim = (int64_t)1 << 31;
+    const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
+    bool fast = (d->k % BK) == 0 && nw * d->k < lim;
+    if (d->conv) {
+      fast = fast && (d->cin % BK) == 0 && (int64_t)d->rows / (d->hout * d->wout) * d->hin * d->win * d->cin < lim;
+    } else {
+      fast = fast && (int64_t)d->rows * d->lda < lim;
+      if (d->a2) fast = fast && (d->k1 % BK) == 0 && (int64_t)d->rows * d->lda2 < lim;
+    }
+    p.fast = fast ? 1 : 0;
+  }
   p.partial = nullptr;
   if (pl.split > 1) {
     const int64_t need = (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
