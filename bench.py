@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
     ap.add_argument("--hoist-invariant", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="run ControlNet branches and the UNet encoder on one stream (default: 3 streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -166,7 +168,8 @@ def main():
 
     unet, cns = build_models(dtype, device)
     den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
-                      hoist_invariant=args.hoist_invariant, use_graph=not args.no_graph)
+                      hoist_invariant=args.hoist_invariant, use_graph=not args.no_graph,
+                      parallel_branches=not args.serial_branches)
     graph_ok = not args.no_graph
     with torch.no_grad():
         den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank))
@@ -241,7 +244,7 @@ def main():
                                "branches (ORS panorama + ORS-3D, SFA on), CFG 2.0 -> 12 view-instances/scene, "
                                "DDIM-50 schedule, random-init weights",
                    "scenes_per_gpu": args.scenes, "parallelism": "scene-sharded x%d (no data-path collective)" % world,
-                   "hip_graph": graph_ok, "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
+                   "hip_graph": graph_ok, "streams": 1 if args.serial_branches else 3, "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
                    "algorithmic_tflop_per_step": step_tflop},
         "model_tflops": value * step_tflop,
         "outputs_finite": finite,

@@ -219,7 +219,14 @@ class UNet2DConditionModelMultiview(ModelBase):
 
     def forward_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, down_res=None, mid_res=None):
         """x: (m*h*w, 8) NHWC latents (4 channels zero-padded to 8); residuals: NHWC 2-D tensors in
-        skip order.  Returns eps as (m, 4, h, w) NCHW."""
+        skip order (each entry a tensor or a tuple of tensors to be summed).  Returns eps as
+        (m, 4, h, w) NCHW."""
+        state = self.encode_nhwc(x, m, h, w, t_f32, ctx2d, lc)
+        return self.decode_nhwc(state, down_res, mid_res)
+
+    def encode_nhwc(self, x, m, h, w, t_f32, ctx2d, lc):
+        """conv_in + down path + mid block — everything that does NOT depend on the ControlNet
+        residuals, so a sampler can overlap it with the ControlNet branches on other streams."""
         dt = self.dtype
         # 1. time (unet_2d_condition_multiview.py:404-411)
         emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
@@ -232,13 +239,27 @@ class UNet2DConditionModelMultiview(ModelBase):
         for blk in self.down_blocks:
             x, h, w, s = run_down_block(blk, x, m, h, w, temb, ctx2d, lc)
             skips += s
-        # ControlNet residual add on the skips (:464-473)
+        # 4. mid (:476-485); its input is the un-augmented down output, the residual is added after
+        x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc)
+        return {"x": x, "m": m, "h": h, "w": w, "skips": skips, "temb": temb, "ctx2d": ctx2d, "lc": lc,
+                "forward_size": forward_size}
+
+    def decode_nhwc(self, state, down_res=None, mid_res=None):
+        x, m, h, w = state["x"], state["m"], state["h"], state["w"]
+        skips, temb, ctx2d, lc = list(state["skips"]), state["temb"], state["ctx2d"], state["lc"]
+
+        def plus(t, r):
+            if isinstance(r, (tuple, list)):
+                return O.add(t, r[0], r[1]) if len(r) == 2 else O.add(t, r[0])
+            return O.add(t, r)
+
+        # ControlNet residual add on the skips (:464-473) and on the mid output (:487-488)
         if down_res is not None:
             if len(down_res) != len(skips):
                 raise ValueError("expected %d down-block residuals, got %d" % (len(skips), len(down_res)))
-            skips = [(O.add(s, r), sh, sw) for (s, sh, sw), r in zip(skips, down_res)]
-        # 4. mid (+ residual, :476-488; folded into the last resnet's epilogue)
-        x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc, extra_res=mid_res)
+            skips = [(plus(s, r), sh, sw) for (s, sh, sw), r in zip(skips, down_res)]
+        if mid_res is not None:
+            x = plus(x, mid_res)
         # 5. up (:491-516)
         for i, blk in enumerate(self.up_blocks):
             final = i == len(self.up_blocks) - 1
@@ -246,7 +267,7 @@ class UNet2DConditionModelMultiview(ModelBase):
             up_size = None
             if not final:
                 nxt = skips[-k - 1]
-                up_size = (nxt[1], nxt[2]) if forward_size else None
+                up_size = (nxt[1], nxt[2]) if state["forward_size"] else None
             x, h, w = run_up_block(blk, x, m, h, w, skips, temb, ctx2d, lc, up_size)
         # 6. post-process (:519-522): GN + SiLU fused, conv_out writes NCHW directly
         a = self.conv_norm_out.run(x, m, h * w, True)

@@ -22,8 +22,9 @@ class KernelTimer:
     bracketed by events recorded on the stream the kernel is launched on; `summary()` groups the
     launches by kernel symbol and returns count, total time and algorithmic FLOPs."""
 
-    def __init__(self):
+    def __init__(self, shapes=False):
         self.records = []
+        self.shapes = shapes
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -136,8 +137,10 @@ def _ptr(t):
 
 
 def workspace(nbytes, device):
-    """Grow-only fp32 scratch buffer per device (allocate before graph capture)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only fp32 scratch buffer per (device, stream): kernels on concurrent streams must not
+    share split-K / GroupNorm scratch.  Allocate before graph capture (eager warm-up)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
     ws = _WS.get(key)
     need = max(int(nbytes), _WS_MIN_BYTES)
     if ws is None or ws.numel() * 4 < need:
@@ -206,7 +209,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     if _TIMER is not None:
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
-        _TIMER.stop(e0, _kname(lib, d),
+        _TIMER.stop(e0, _kname(lib, d) + (" gemm %dx%dx%d" % (rows, n_w, k) if _TIMER.shapes else ""),
                     2.0 * rows * n_w * k, 2.0 * (rows * k + n_w * k + rows * n))
         return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
@@ -263,7 +266,7 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     if _TIMER is not None:
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
-        _TIMER.stop(e0, _kname(lib, d),
+        _TIMER.stop(e0, _kname(lib, d) + (" conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else ""),
                     2.0 * rows * cout * 9 * cin, 2.0 * (x.numel() + w.numel() + rows * cout))
         return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")

@@ -46,7 +46,8 @@ class BEVDenoiser:
     """One scene batch (b scenes x n_cam views) of CFG denoising with 1 or 2 ControlNet branches."""
 
     def __init__(self, unet, controlnets: List, guidance_scale=2.0, num_inference_steps=50,
-                 conditioning_scale=1.0, hoist_invariant=False, use_graph=True, use_aug_text=False):
+                 conditioning_scale=1.0, hoist_invariant=False, use_graph=True, use_aug_text=False,
+                 parallel_branches=True):
         self.unet = unet
         self.controlnets = list(controlnets)
         self.guidance_scale = float(guidance_scale)
@@ -58,6 +59,11 @@ class BEVDenoiser:
         self.timesteps, self.coef_table = ddim_schedule(num_inference_steps)
         self._graph = None
         self._prepared = None
+        # The ControlNet branches and the UNet encoder (conv_in + down + mid) are mutually
+        # independent until the residual add: run them on separate HIP streams (fork / join inside
+        # the captured graph) so the small deep-level kernels of one fill the CUs the others leave idle.
+        self.parallel_branches = parallel_branches
+        self._side = None
 
     # ---------------------------------------------------------------------------- inputs ----
     def set_inputs(self, latents, prompt_embeds, camera_param, bboxes_list, conds):
@@ -100,14 +106,47 @@ class BEVDenoiser:
     def _step_body(self):
         m, h, w = self.m, self.h, self.w
         x8 = O.nchw_to_nhwc(self.lat2.reshape(m, 4, h, w), 8)           # latent_model_input, NHWC pad 8
-        prep = self._prepared if self._prepared is not None else self._prepare()
-        res = None
-        for i, cn in enumerate(self.controlnets):                        # :405-431
-            res = cn.forward_nhwc(x8, m, h, w, self.t_dev, prep[i], self.conditioning_scale,
-                                  out=res, accumulate=i > 0)
-        ctx = prep[0]                                                    # tokens from branch 0 (:430-431)
-        eps = self.unet.forward_nhwc(x8, m, h, w, self.t_dev, ctx["ctx2d"], ctx["lc"],
-                                     [r[0] for r in res[:-1]], res[-1][0])      # :476-484
+        n = len(self.controlnets)
+        if not self.parallel_branches:
+            prep = self._prepared if self._prepared is not None else self._prepare()
+            res = None
+            for i, cn in enumerate(self.controlnets):                    # :405-431, sum in the epilogue
+                res = cn.forward_nhwc(x8, m, h, w, self.t_dev, prep[i], self.conditioning_scale,
+                                      out=res, accumulate=i > 0)
+            ctx = prep[0]                                                # tokens from branch 0 (:430-431)
+            eps = self.unet.forward_nhwc(x8, m, h, w, self.t_dev, ctx["ctx2d"], ctx["lc"],
+                                         [r[0] for r in res[:-1]], res[-1][0])      # :476-484
+        else:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = [torch.cuda.Stream() for _ in range(n)]
+            # branch 0's tokens feed the UNet, so its conditioning is prepared on the main stream
+            prep0 = self._prepared[0] if self._prepared is not None else \
+                self.controlnets[0].prepare_condition(self.camera_param, self.bboxes_list[0], self.prompt_embeds,
+                                                      self.conds[0], self.use_aug_text)
+            results = [None] * n
+            for i, cn in enumerate(self.controlnets):                    # fork
+                s = self._side[i]
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    if i == 0:
+                        p_i = prep0
+                    elif self._prepared is not None:
+                        p_i = self._prepared[i]
+                    else:
+                        p_i = cn.prepare_condition(self.camera_param, self.bboxes_list[i], self.prompt_embeds,
+                                                   self.conds[i], self.use_aug_text)
+                    results[i] = cn.forward_nhwc(x8, m, h, w, self.t_dev, p_i, self.conditioning_scale)
+            state = self.unet.encode_nhwc(x8, m, h, w, self.t_dev, prep0["ctx2d"], prep0["lc"])
+            for s in self._side:                                         # join
+                main.wait_stream(s)
+            if n == 1:
+                down = [r[0] for r in results[0][:-1]]
+                mid = results[0][-1][0]
+            else:                                                        # branch sum (:421-429) in the add
+                down = [tuple(results[i][j][0] for i in range(n)) for j in range(len(results[0]) - 1)]
+                mid = tuple(results[i][-1][0] for i in range(n))
+            eps = self.unet.decode_nhwc(state, down, mid)
         O.cfg_ddim_step(eps, self.lat2[0], self.coef, self.guidance_scale,
                         x_out=self.lat2[0], x_dup=self.lat2[1])          # :487-499
         return eps
