@@ -15,6 +15,10 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libdualdiff_hip.so"
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+# per-source extra flags: the attention softmax lives on the MFMA results, so ask LLVM for the
+# VGPR-destination form of MFMA (gfx950 has a unified register file) instead of AGPR accumulators
+# that cost a v_accvgpr_read/write per touched element.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]}
 ARCH = "gfx950"
 
 
@@ -54,7 +58,7 @@ def build_native(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -40,8 +40,11 @@ void dd_attn_kernel(const AttnParams p) {
   constexpr int DQ = (D + 31) / 32 * 32;       // padded head dim for QK^T
   constexpr int KSTEPS = DQ / 32;
   constexpr int DVT = (D + 15) / 16;           // 16-wide d tiles for PV
-  constexpr int KSTR = DQ + 8;                 // LDS row strides (elements)
-  constexpr int VSTR = DVT * 16 + 8;
+  // LDS row strides (elements).  Pads chosen by enumerating the bank pattern of the ds_read_b128
+  // lane groups (K) and of the ds_read_b64_tr_b16 halves (V): +32 B per K row is conflict-free for
+  // all three head dims; V rows need no pad at d = 40 / 80 and +32 B at d = 160.
+  constexpr int KSTR = DQ + 16;
+  constexpr int VSTR = DVT * 16 + (D == 160 ? 16 : 0);
   constexpr int KCH = DQ / 8;                  // 16-B chunks per K row in LDS
   constexpr int VCH = DVT * 2;                 // 16-B chunks per V row in LDS
   constexpr int DCH = D / 8;                   // valid chunks per global row
@@ -282,7 +285,7 @@ template <typename T, int D, int QT, bool TR, int KV_TILE>
 int launch_attn(const AttnParams& p, hipStream_t s) {
   constexpr int DQ = (D + 31) / 32 * 32;
   constexpr int DVT = (D + 15) / 16;
-  constexpr size_t smem = (size_t)KV_TILE * ((DQ + 8) + (DVT * 16 + 8)) * sizeof(T);
+  constexpr size_t smem = (size_t)KV_TILE * ((DQ + 16) + (DVT * 16 + (D == 160 ? 16 : 0))) * sizeof(T);
   const int qblk = 4 * QT * 16;
   dim3 grid((p.lq + qblk - 1) / qblk, p.batch * p.heads);
   hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR, KV_TILE>), grid, dim3(256), smem, s, p);

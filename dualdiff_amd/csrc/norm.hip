@@ -123,16 +123,34 @@ template <typename T>
 __global__ __launch_bounds__(GN_THREADS)
 void dd_gn_apply_kernel(const GnParams p) {
   __shared__ float s_mean[64], s_rstd[64];
+  __shared__ float s_ps[GN_THREADS], s_pq[GN_THREADS];
   const int split = blockIdx.x, inst = blockIdx.y;
-  if (threadIdx.x < p.groups) {
+  {
+    // combine the per-split partial sums: all 256 threads fetch in parallel (chunk-strided), then
+    // one thread per group adds the chunk sums in a fixed order (bit-reproducible).
+    const int g = threadIdx.x % p.groups;
+    const int chunk = threadIdx.x / p.groups;
+    const int nchunk = GN_THREADS / p.groups;
     float s = 0.f, ss = 0.f;
-    const float* src = p.ws + ((int64_t)inst * p.nsplit * p.groups + threadIdx.x) * 2;
-    for (int i = 0; i < p.nsplit; ++i) { s += src[0]; ss += src[1]; src += p.groups * 2; }
-    const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
-    const float mean = s * inv_n;
-    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-    s_mean[threadIdx.x] = mean;
-    s_rstd[threadIdx.x] = rsqrtf(var + p.eps);
+    if (chunk < nchunk) {
+      const float* src = p.ws + ((int64_t)inst * p.nsplit * p.groups + g) * 2;
+      for (int i = chunk; i < p.nsplit; i += nchunk) {
+        s += src[(int64_t)i * p.groups * 2];
+        ss += src[(int64_t)i * p.groups * 2 + 1];
+      }
+    }
+    s_ps[threadIdx.x] = s;
+    s_pq[threadIdx.x] = ss;
+    __syncthreads();
+    if (threadIdx.x < p.groups) {
+      float a = 0.f, b = 0.f;
+      for (int c = 0; c < nchunk; ++c) { a += s_ps[c * p.groups + threadIdx.x]; b += s_pq[c * p.groups + threadIdx.x]; }
+      const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
+      const float mean = a * inv_n;
+      const float var = fmaxf(b * inv_n - mean * mean, 0.f);
+      s_mean[threadIdx.x] = mean;
+      s_rstd[threadIdx.x] = rsqrtf(var + p.eps);
+    }
   }
   __syncthreads();
   const GnMap mp = gn_map(p.c);
