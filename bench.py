@@ -196,10 +196,8 @@ def main():
             den.step((args.warmup + i) % 50)
         barrier()
         elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        from dualdiff_amd.parallel import max_over_ranks
+        elapsed = max_over_ranks(elapsed, device)          # slowest rank sets the job's wall time
         finite = bool(torch.isfinite(den.latents.float()).all().item())
 
         roofline = None

@@ -62,8 +62,22 @@ __device__ __forceinline__ u32x4 dd_pack8(const float (&f)[8]) {
 }
 
 __device__ __forceinline__ float dd_silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16/bf16 resolution): one rcp, one
+// exp and five fmas instead of libm's ~40-instruction erff — the GEGLU epilogue evaluates it on
+// 21.5 M gate values per L0 feed-forward.
+__device__ __forceinline__ float dd_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float r = 1.0f - p * t * e;
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float dd_gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + dd_erf_fast(x * 0.70710678118654752440f));
 }
 
 __device__ __forceinline__ float dd_wave_sum(float v) {

@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what include/dualdiff_hip.h declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dualdiff_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_hot_path():
+    fns = header_functions()
+    for name in ("dd_gemm", "dd_attention", "dd_groupnorm_nhwc", "dd_layernorm", "dd_cfg_ddim_step",
+                 "dd_timestep_embedding", "dd_add", "dd_conv3x3_small_cout"):
+        assert name in fns
+
+
+def test_library_exports_every_declared_symbol():
+    from dualdiff_amd import _build, _native
+    if not os.path.exists(_build.lib_path()):
+        pytest.skip("library not built (run __graft_entry__.build())")
+    lib = _native.load(build_if_missing=False)
+    declared = header_functions()
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in the header but not exported" % name
+    assert sorted(_native.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
+    assert lib.dd_abi_version() == 1
+    assert lib.dd_target_arch() == b"gfx950"
+    assert b"workspace" in lib.dd_error_string(-4)
+
+
+def test_validation_without_a_gpu():
+    """Argument validation runs before any launch: bad descriptors are rejected on a CPU-only box."""
+    import ctypes
+    from dualdiff_amd import _build, _native
+    if not os.path.exists(_build.lib_path()):
+        pytest.skip("library not built")
+    lib = _native.load(build_if_missing=False)
+    d = _native.GemmDesc()
+    assert lib.dd_gemm(ctypes.byref(d), None) == -1            # null pointers
+    d.a = d.w = d.out = 16
+    d.rows, d.n, d.k, d.k1, d.lda, d.ldc, d.alpha, d.dtype = 8, 12, 64, 64, 64, 12, 1.0, 1
+    assert lib.dd_gemm(ctypes.byref(d), None) == -1            # n % 8 != 0
+    a = _native.AttnDesc()
+    a.q = a.k = a.v = a.o = 16
+    a.batch, a.heads, a.head_dim, a.lq, a.lk = 1, 8, 64, 4, 4
+    a.ldq = a.ldk = a.ldv = a.ldo = 512
+    assert lib.dd_attention(ctypes.byref(a), None) == -2       # head_dim 64 unsupported
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    import torch
+    from dualdiff_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))
