@@ -35,6 +35,7 @@ struct GemmParams {
   int k_per_split;
   float* partial;
   int tiles_m, tiles_n;
+  uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
   int fast;            // 64-aligned K structure + 32-bit element offsets: cheap DMA address path
 };
 
@@ -354,6 +355,15 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// buffer_load_dwordx4 ... offen lds: SGPR descriptor + one 32-bit byte offset per lane.  An offset
+// outside the descriptor's range reads zeros (hardware range check), which is how padding taps and
+// tile tails are produced on the fast path — no 64-bit pointer arithmetic, no select against a zero page.
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           (int)byte_off, 0, 0, 0);
+}
+constexpr uint32_t DD_OOB = 0xFFFFFFF0u;
+
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 void dd_gemm2_kernel(const GemmParams p) {
@@ -539,26 +549,27 @@ void dd_gemm2_kernel(const GemmParams p) {
     }
   }
   // src = valid ? base + 2*off : zero page, branch-free (exactly one DMA instruction per call)
-  auto src_of = [&](uintptr_t base, uint32_t off_elems, uint32_t mask) __attribute__((always_inline)) -> const void* {
-    const uintptr_t real = base + ((uintptr_t)off_elems << 1);
-    const uintptr_t m = (uintptr_t)(int64_t)(int32_t)mask;
-    return reinterpret_cast<const void*>(zaddr + ((real - zaddr) & m));
+  // byte offset for the descriptor DMA: real offset when valid (mask all-ones), else out of range
+  auto voff = [&](uint32_t off_elems, uint32_t mask) __attribute__((always_inline)) -> uint32_t {
+    return ((off_elems << 1) & mask) | (DD_OOB & ~mask);
   };
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
   auto issue_fast = [&](int kt, int slot) __attribute__((always_inline)) {
     const int k0 = kbeg + kt * BK;                    // scalar
     const uint32_t kl = (uint32_t)(k0 + lc * 8);
     T* xs = ring + slot * STAGE;
     T* ws = xs + BM * BK;
-    const uintptr_t wb = reinterpret_cast<uintptr_t>(p.w);
 #pragma unroll
-    for (int j = 0; j < WI; ++j) glds16(src_of(wb, wrow[j] + kl, wmask[j]), ws + (j * NW + wave) * 8 * BK);
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, voff(wrow[j] + kl, wmask[j]), ws + (j * NW + wave) * 8 * BK);
     if (CONV) {
       const int tap = k0 / p.cin;                     // scalar: 64 | cin
       const int ci0 = k0 - tap * p.cin;
       const int ky = tap / 3;
       const int kx = tap - ky * 3;
       const uint32_t cl = (uint32_t)(ci0 + lc * 8);
-      const uintptr_t ab = reinterpret_cast<uintptr_t>(p.a);
       if (p.upsample) {                               // scalar branch; both arms issue XI DMAs
         // table select by mask arithmetic (a select of array elements would force the tables to scratch)
         const uint32_t y0 = 0u - (uint32_t)(ky == 0), y1 = 0u - (uint32_t)(ky == 1), y2 = 0u - (uint32_t)(ky == 2);
@@ -568,25 +579,23 @@ void dd_gemm2_kernel(const GemmParams p) {
           const uint32_t oy = (syo[j][0] & y0) | (syo[j][1] & y1) | (syo[j][2] & y2);
           const uint32_t ox = (sxo[j][0] & x0) | (sxo[j][1] & x1) | (sxo[j][2] & x2);
           const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
-          glds16(src_of(ab, oy + ox + cl, m), xs + (j * NW + wave) * 8 * BK);
+          bdma16(rs_a, voff(oy + ox + cl, m), xs + (j * NW + wave) * 8 * BK);
         }
       } else {
         const uint32_t toff = (uint32_t)((ky * p.win + kx) * p.cin) + cl;
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
           const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
-          glds16(src_of(ab, xrow[j] + toff, m), xs + (j * NW + wave) * 8 * BK);
+          bdma16(rs_a, voff(xrow[j] + toff, m), xs + (j * NW + wave) * 8 * BK);
         }
       }
     } else if (k0 >= p.k1) {                          // scalar: 64 | k1
-      const uintptr_t ab = reinterpret_cast<uintptr_t>(p.a2);
       const uint32_t kk = kl - (uint32_t)p.k1;
 #pragma unroll
-      for (int j = 0; j < XI; ++j) glds16(src_of(ab, xrow2[j] + kk, xmask[j]), xs + (j * NW + wave) * 8 * BK);
+      for (int j = 0; j < XI; ++j) bdma16(rs_a2, voff(xrow2[j] + kk, xmask[j]), xs + (j * NW + wave) * 8 * BK);
     } else {
-      const uintptr_t ab = reinterpret_cast<uintptr_t>(p.a);
 #pragma unroll
-      for (int j = 0; j < XI; ++j) glds16(src_of(ab, xrow[j] + kl, xmask[j]), xs + (j * NW + wave) * 8 * BK);
+      for (int j = 0; j < XI; ++j) bdma16(rs_a, voff(xrow[j] + kl, xmask[j]), xs + (j * NW + wave) * 8 * BK);
     }
   };
   auto issue_any = [&](int kt, int slot) __attribute__((always_inline)) {
@@ -907,6 +916,17 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
       if (d->a2) fast = fast && (d->k1 % BK) == 0 && (int64_t)d->rows * d->lda2 < lim;
     }
     p.fast = fast ? 1 : 0;
+  }
+  {
+    const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
+    p.w_bytes = (uint32_t)(nw * d->k * 2);
+    if (d->conv) {
+      p.a_bytes = (uint32_t)((int64_t)d->rows / (d->hout * d->wout) * d->hin * d->win * d->cin * 2);
+      p.a2_bytes = 0;
+    } else {
+      p.a_bytes = (uint32_t)((((int64_t)d->rows - 1) * d->lda + p.k1) * 2);
+      p.a2_bytes = d->a2 ? (uint32_t)((((int64_t)d->rows - 1) * d->lda2 + (d->k - d->k1)) * 2) : 0u;
+    }
   }
   p.partial = nullptr;
   if (pl.split > 1) {
