@@ -35,8 +35,8 @@ PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
 H, W, NCAM, NBOX, LTXT = 28, 50, 6, 20, 77
 # algorithmic work, GFLOP per view-instance
 GF_UNET, GF_CNET = 324.1, 84.7
+PEAK_HBM_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
-PEAK_HBM_GBPS = 8000.0
 
 
 def build_models(dtype, device, dual=True):
@@ -134,6 +134,21 @@ def _metric_name():
         return "denoising-steps/sec, 6-view 224x400, 50-step DDIM"
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes, see tools/pmc_summary.py); None when the profile has no such kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, row in table.items():
+        if kernel in name:
+            return row["hbm_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +162,8 @@ def main():
                     help="run ControlNet branches and the UNet encoder on one stream (default: 3 streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tune-cache", default=os.environ.get("DD_TUNE_CACHE"),
+                    help="load the tile/split-K table from this file if present, write it after warm-up")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,6 +183,8 @@ def main():
     from dualdiff_amd import ops as O
     from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
 
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        O.load_tuned(args.tune_cache)
     unet, cns = build_models(dtype, device)
     den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
                       hoist_invariant=args.hoist_invariant, use_graph=not args.no_graph,
@@ -191,6 +210,8 @@ def main():
         for i in range(args.warmup):
             den.step(i % 50)
         barrier()
+        if args.tune_cache and rank == 0 and not os.path.exists(args.tune_cache):
+            O.save_tuned(args.tune_cache)
         t0 = time.perf_counter()
         for i in range(args.steps):
             den.step((args.warmup + i) % 50)
@@ -204,16 +225,30 @@ def main():
         if rank == 0 and not args.no_roofline:
             timer = O.KernelTimer()
             O.set_timer(timer)
+            par = den.parallel_branches
+            den.parallel_branches = False     # one stream: event pairs must not see co-running branches
             den._step_body()                  # instrumented eager step: HIP events around each launch
+            den.parallel_branches = par
             O.set_timer(None)
             summ = timer.summary()
             name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            avg_ms = d["ms"] / d["count"]
-            achieved = d["flops"] / d["count"] / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": name, "launches_per_step": d["count"],
-                        "avg_us": avg_ms * 1e3, "share_of_timed_kernels": d["ms"] / sum(v["ms"] for v in summ.values()),
-                        "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": None}
+            avg_s = d["ms"] / d["count"] * 1e-3
+            tflops = d["flops"] / d["count"] / avg_s / 1e12
+            gbps = d["bytes"] / d["count"] / avg_s / 1e9
+            # the bound is the roof the kernel's ALGORITHMIC intensity puts it under
+            ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
+            hbm_bound = d["flops"] / max(d["bytes"], 1.0) < ridge
+            roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+                        "launches_per_step": d["count"], "avg_us": avg_s * 1e6,
+                        "share_of_timed_kernels": d["ms"] / sum(v["ms"] for v in summ.values()),
+                        "achieved": gbps if hbm_bound else tflops,
+                        "peak": PEAK_HBM_GBPS if hbm_bound else PEAK_MFMA_TFLOPS,
+                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                        "frac": gbps / PEAK_HBM_GBPS if hbm_bound else tflops / PEAK_MFMA_TFLOPS,
+                        "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
+                        "algorithmic_flops_per_launch": d["flops"] / d["count"],
+                        "other_roof_frac": tflops / PEAK_MFMA_TFLOPS if hbm_bound else gbps / PEAK_HBM_GBPS,
+                        "traffic": _pmc_traffic(name)}
             if os.environ.get("DD_BENCH_KERNEL_TABLE"):
                 rows = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
                 with open(os.environ["DD_BENCH_KERNEL_TABLE"], "w") as f:

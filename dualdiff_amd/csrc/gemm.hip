@@ -36,7 +36,6 @@ struct GemmParams {
   float* partial;
   int tiles_m, tiles_n;
   uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
-  int fast;            // 64-aligned K structure + 32-bit element offsets: cheap DMA address path
 };
 
 // --- epilogue on 8 consecutive output channels of one row --------------------------------
@@ -338,31 +337,27 @@ void dd_gemm_kernel(const GemmParams p) {
 }
 
 // =============================================================================================
-// Kernel family 2: LDS-DMA (global_load_lds, 16 B / lane) multi-stage ring.
+// Kernel family 2: LDS-DMA (buffer_load_dwordx4 ... lds, 16 B / lane) multi-stage ring.
 //  * no staging registers and no ds_write: tiles land in LDS asynchronously, NSTAGE-1 K-steps ahead;
-//  * the XOR swizzle is applied on the per-lane SOURCE address (the DMA destination is lane-linear);
-//  * padding / tails read a zero page instead of being predicated (DMA cannot write zeros itself);
+//  * the XOR swizzle is applied on the per-lane SOURCE offset (the DMA destination is lane-linear);
+//  * padding taps / tile tails use an out-of-range lane offset: the descriptor's range check makes
+//    the DMA deliver zeros, so nothing is predicated;
 //  * counted s_waitcnt vmcnt(N) + raw s_barrier: one barrier per K-step, loads stay in flight
 //    across it.
 // =============================================================================================
-__device__ __attribute__((aligned(256))) unsigned char dd_zero_page[256];
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// buffer_load_dwordx4 ... offen lds: SGPR descriptor + one 32-bit byte offset per lane.  An offset
-// outside the descriptor's range reads zeros (hardware range check), which is how padding taps and
-// tile tails are produced on the fast path — no 64-bit pointer arithmetic, no select against a zero page.
-__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, void* lds_wave_base) {
+// buffer_load_dwordx4 ... offen lds: SGPR descriptor + a 32-bit byte offset per lane + a scalar
+// offset.  An offset outside the descriptor's range reads zeros (hardware range check), which is how
+// padding taps and tile tails are produced — no 64-bit pointer arithmetic, no select against a zero page.
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, void* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
-                                           (int)byte_off, 0, 0, 0);
+                                           (int)voff, (int)soff, 0, 0);
 }
-constexpr uint32_t DD_OOB = 0xFFFFFFF0u;
+// every buffer is < 2^31 bytes (checked on the host), so this lane offset is out of range whatever
+// scalar offset is added to it
+constexpr uint32_t DD_OOB = 0x80000000u;
 
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
@@ -406,201 +401,128 @@ void dd_gemm2_kernel(const GemmParams p) {
   // even number of waves does not depend on j.
   const int lrow = lane >> 3;
   const int lc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
-  const T* zero = reinterpret_cast<const T*>(dd_zero_page);
+  const uint32_t lcb = (uint32_t)lc * 16u;          // this lane's 16-B chunk inside the 128-B K segment
 
-  int xm[XI], xiy[XI], xix[XI];
-#pragma unroll
-  for (int j = 0; j < XI; ++j) {
-    const int r = block_m0 + (j * NW + wave) * 8 + lrow;
-    if (r < p.rows) {
-      if (CONV) {
-        const int hw = p.hout * p.wout;
-        const int inst = r / hw;
-        const int rem = r - inst * hw;
-        const int oy = rem / p.wout;
-        const int ox = rem - oy * p.wout;
-        xm[j] = inst;
-        xiy[j] = oy * p.stride - 1;
-        xix[j] = ox * p.stride - 1;
-      } else {
-        xm[j] = r; xiy[j] = 0; xix[j] = 0;
-      }
-    } else {
-      xm[j] = -1; xiy[j] = 0; xix[j] = 0;
-    }
-  }
-  int64_t wofs[WI];
+  // All address state lives in per-lane byte-offset tables that change at most once per conv tap
+  // (or at the a/a2 seam); a K-step only moves SCALAR offsets.  K, cin and k1 are multiples of 64
+  // here (the host routes other shapes to the register-staged family), so a K-step never straddles
+  // a tap or the seam.  Exactly ONE DMA instruction per (operand, j) and stage: the counted vmcnt
+  // waits below rely on it.
+  uint32_t wv[WI];                                  // weight rows: n * K * 2 + chunk, or out of range
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
     const int R = (j * NW + wave) * 8 + lrow;
-    const int wv = R / (TN * 16);
+    const int wvi = R / (TN * 16);
     const int rho = R % (TN * 16);
     const int tn = rho >> 4, r = rho & 15;
     int n_glob;
     if (GEGLU) {
       constexpr int TH = TN / 2;
       const int t = tn % TH;
-      const int loc = wv * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
+      const int loc = wvi * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
       const int col = block_n0 + loc;
       n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
     } else {
-      const int loc = wv * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
+      const int loc = wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
       const int col = block_n0 + loc;
       n_glob = (col < p.n) ? col : -1;
     }
-    wofs[j] = (n_glob >= 0) ? (int64_t)n_glob * p.k : -1;
+    wv[j] = n_glob >= 0 ? (uint32_t)n_glob * (uint32_t)p.k * 2u + lcb : DD_OOB;
   }
 
-  // Exactly ONE DMA instruction per (operand, j) and stage — the counted vmcnt waits below rely on
-  // it — so the real / zero-page source is selected arithmetically, never by a branch.
-  auto pick = [&](const T* real, bool valid) __attribute__((always_inline)) -> const T* {
-    const uintptr_t z = reinterpret_cast<uintptr_t>(zero);
-    const uintptr_t m = valid ? ~(uintptr_t)0 : (uintptr_t)0;
-    return reinterpret_cast<const T*>(z + ((reinterpret_cast<uintptr_t>(real) - z) & m));
-  };
-  auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
-    const int k = kbeg + kt * BK + lc * 8;
-    const bool kok = k < kend;
-    T* xs = ring + slot * STAGE;
-    T* ws = xs + BM * BK;
+  uint32_t xe[XI];                                  // activation rows: offsets for the current tap / source a
+  uint32_t xe2[CONV ? 1 : XI];                      // dense: offsets into a2
+  uint32_t syo[CONV ? XI : 1][3], sxo[CONV ? XI : 1][3], xbits[CONV ? XI : 1];   // conv: per-tap source offsets
 #pragma unroll
-    for (int j = 0; j < WI; ++j) {
-      const int64_t wo = wofs[j] < 0 ? 0 : wofs[j];
-      glds16(pick(reinterpret_cast<const T*>(p.w) + wo + k, kok && wofs[j] >= 0), ws + (j * NW + wave) * 8 * BK);
-    }
+  for (int j = 0; j < XI; ++j) {
+    const int r = block_m0 + (j * NW + wave) * 8 + lrow;
+    const bool rv = r < p.rows;
     if (CONV) {
-      const int tap = k / p.cin;
-      const int ci = k - tap * p.cin;
-      const int ky = tap / 3;
+      const int hw = p.hout * p.wout;
+      const int rr = rv ? r : 0;
+      const int inst = rr / hw;
+      const int rem = rr - inst * hw;
+      const int oy = rem / p.wout;
+      const int ox = rem - oy * p.wout;
+      const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int iy = iy0 + t, ix = ix0 + t;
+        const bool vy = iy >= 0 && iy < p.hv, vx = ix >= 0 && ix < p.wv;
+        int sy = min(max(iy, 0), p.hv - 1), sx = min(max(ix, 0), p.wv - 1);
+        if (p.upsample) {                             // torch nearest: min(floor(dst * in/out), in - 1)
+          sy = min((int)floorf(sy * p.scale_h), p.hin - 1);
+          sx = min((int)floorf(sx * p.scale_w), p.win - 1);
+        }
+        syo[j][t] = (uint32_t)((inst * p.hin + sy) * p.win) * (uint32_t)p.cin * 2u + lcb;
+        sxo[j][t] = (uint32_t)(sx * p.cin) * 2u;
+        if (vy) bits |= 1u << t;
+        if (vx) bits |= 8u << t;
+      }
+      uint32_t m9 = 0;                                // bit (ky*3+kx): tap reads a real pixel
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if (rv && ((bits >> (t / 3)) & 1u) && ((bits >> (3 + t % 3)) & 1u)) m9 |= 1u << t;
+      xbits[j] = m9;
+      xe[j] = DD_OOB;
+    } else {
+      xe[j] = rv ? (uint32_t)r * (uint32_t)p.lda * 2u + lcb : DD_OOB;
+      xe2[j] = rv ? (uint32_t)r * (uint32_t)p.lda2 * 2u + lcb : DD_OOB;
+    }
+  }
+  // conv: point xe[] at tap `tap` (table select by mask arithmetic: a select of array elements
+  // would force the tables to scratch)
+  auto set_tap = [&](int tap) __attribute__((always_inline)) {
+    if (CONV) {
+      const int ky = (tap * 11) >> 5;                 // tap / 3 for tap in [0, 9]
       const int kx = tap - ky * 3;
+      const uint32_t y0 = 0u - (uint32_t)(ky == 0), y1 = 0u - (uint32_t)(ky == 1), y2 = 0u - (uint32_t)(ky == 2);
+      const uint32_t x0 = 0u - (uint32_t)(kx == 0), x1 = 0u - (uint32_t)(kx == 1), x2 = 0u - (uint32_t)(kx == 2);
 #pragma unroll
       for (int j = 0; j < XI; ++j) {
-        int iy = xiy[j] + ky, ix = xix[j] + kx;
-        const bool valid = kok && xm[j] >= 0 && iy >= 0 && iy < p.hv && ix >= 0 && ix < p.wv;
-        iy = min(max(iy, 0), p.hv - 1);
-        ix = min(max(ix, 0), p.wv - 1);
-        if (p.upsample) {                    // wave-uniform
-          iy = min((int)floorf(iy * p.scale_h), p.hin - 1);
-          ix = min((int)floorf(ix * p.scale_w), p.win - 1);
-        }
-        const int64_t off = (((int64_t)max(xm[j], 0) * p.hin + iy) * p.win + ix) * p.cin + ci;
-        glds16(pick(reinterpret_cast<const T*>(p.a) + off, valid), xs + (j * NW + wave) * 8 * BK);
-      }
-    } else {
-      const bool second = k >= p.k1;
-      const T* base = second ? reinterpret_cast<const T*>(p.a2) : reinterpret_cast<const T*>(p.a);
-      const int64_t ld = second ? p.lda2 : p.lda;
-      const int kk = second ? k - p.k1 : k;
-#pragma unroll
-      for (int j = 0; j < XI; ++j)
-        glds16(pick(base + (int64_t)max(xm[j], 0) * ld + kk, kok && xm[j] >= 0), xs + (j * NW + wave) * 8 * BK);
-    }
-  };
-
-  // ---- fast address path (p.fast): K is a multiple of 64 so a K-step never straddles a conv tap or
-  // the a/a2 seam, and all element offsets fit 32 bits.  Per DMA instruction: a few VALU ops on
-  // per-row tables built once, instead of 64-bit index arithmetic with divisions.
-  const uintptr_t zaddr = reinterpret_cast<uintptr_t>(zero);
-  uint32_t wrow[WI], wmask[WI];                 // weight row offset (elements), all-ones if valid
-  uint32_t xrow[XI], xrow2[XI], xmask[XI];      // dense: row offsets into a / a2
-  uint32_t syo[XI][3], sxo[XI][3], xbits[XI];   // conv: source row / column offsets per tap, 9-bit validity
-  if (p.fast) {
-#pragma unroll
-    for (int j = 0; j < WI; ++j) {
-      wmask[j] = wofs[j] >= 0 ? 0xFFFFFFFFu : 0u;
-      wrow[j] = wofs[j] >= 0 ? (uint32_t)wofs[j] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-      const bool rv = xm[j] >= 0;
-      xmask[j] = rv ? 0xFFFFFFFFu : 0u;
-      if (CONV) {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int iy = xiy[j] + t, ix = xix[j] + t;
-          const bool vy = iy >= 0 && iy < p.hv, vx = ix >= 0 && ix < p.wv;
-          int sy = min(max(iy, 0), p.hv - 1), sx = min(max(ix, 0), p.wv - 1);
-          if (p.upsample) {
-            sy = min((int)floorf(sy * p.scale_h), p.hin - 1);
-            sx = min((int)floorf(sx * p.scale_w), p.win - 1);
-          }
-          syo[j][t] = (uint32_t)((max(xm[j], 0) * p.hin + sy) * p.win) * (uint32_t)p.cin;
-          sxo[j][t] = (uint32_t)(sx * p.cin);
-          if (vy) bits |= 1u << t;
-          if (vx) bits |= 8u << t;
-        }
-        // bit (ky*3+kx) of xbits: tap valid
-        uint32_t m9 = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-          if (rv && ((bits >> (t / 3)) & 1u) && ((bits >> (3 + t % 3)) & 1u)) m9 |= 1u << t;
-        xbits[j] = m9;
-        // no upsample: tap (ky,kx) reads pixel (oy0+ky, ox0+kx) -> one per-row base + a scalar tap offset
-        xrow[j] = (uint32_t)(((max(xm[j], 0) * p.hin + xiy[j]) * p.win + xix[j]) * p.cin);
-        xrow2[j] = 0;
-      } else {
-        xrow[j] = rv ? (uint32_t)(xm[j] * (int)p.lda) : 0u;
-        xrow2[j] = rv ? (uint32_t)(xm[j] * (int)p.lda2) : 0u;
-        xbits[j] = 0;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { syo[j][t] = 0; sxo[j][t] = 0; }
+        const uint32_t oy = (syo[j][0] & y0) | (syo[j][1] & y1) | (syo[j][2] & y2);
+        const uint32_t ox = (sxo[j][0] & x0) | (sxo[j][1] & x1) | (sxo[j][2] & x2);
+        const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
+        xe[j] = ((oy + ox) & m) | (DD_OOB & ~m);
       }
     }
-  }
-  // src = valid ? base + 2*off : zero page, branch-free (exactly one DMA instruction per call)
-  // byte offset for the descriptor DMA: real offset when valid (mask all-ones), else out of range
-  auto voff = [&](uint32_t off_elems, uint32_t mask) __attribute__((always_inline)) -> uint32_t {
-    return ((off_elems << 1) & mask) | (DD_OOB & ~mask);
   };
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
-  auto issue_fast = [&](int kt, int slot) __attribute__((always_inline)) {
-    const int k0 = kbeg + kt * BK;                    // scalar
-    const uint32_t kl = (uint32_t)(k0 + lc * 8);
+
+  // issue cursor (all scalar): next K offset, and for conv its tap / channel split
+  int ik0 = kbeg;
+  int itap = CONV ? kbeg / p.cin : 0;
+  int ici0 = CONV ? kbeg - itap * p.cin : 0;
+  set_tap(itap);
+  auto issue_next = [&](int slot) __attribute__((always_inline)) {
     T* xs = ring + slot * STAGE;
     T* ws = xs + BM * BK;
+    const uint32_t ksoff = (uint32_t)ik0 * 2u;
 #pragma unroll
-    for (int j = 0; j < WI; ++j) bdma16(rs_w, voff(wrow[j] + kl, wmask[j]), ws + (j * NW + wave) * 8 * BK);
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], ksoff, ws + (j * NW + wave) * 8 * BK);
     if (CONV) {
-      const int tap = k0 / p.cin;                     // scalar: 64 | cin
-      const int ci0 = k0 - tap * p.cin;
-      const int ky = tap / 3;
-      const int kx = tap - ky * 3;
-      const uint32_t cl = (uint32_t)(ci0 + lc * 8);
-      if (p.upsample) {                               // scalar branch; both arms issue XI DMAs
-        // table select by mask arithmetic (a select of array elements would force the tables to scratch)
-        const uint32_t y0 = 0u - (uint32_t)(ky == 0), y1 = 0u - (uint32_t)(ky == 1), y2 = 0u - (uint32_t)(ky == 2);
-        const uint32_t x0 = 0u - (uint32_t)(kx == 0), x1 = 0u - (uint32_t)(kx == 1), x2 = 0u - (uint32_t)(kx == 2);
+      const uint32_t csoff = (uint32_t)ici0 * 2u;
 #pragma unroll
-        for (int j = 0; j < XI; ++j) {
-          const uint32_t oy = (syo[j][0] & y0) | (syo[j][1] & y1) | (syo[j][2] & y2);
-          const uint32_t ox = (sxo[j][0] & x0) | (sxo[j][1] & x1) | (sxo[j][2] & x2);
-          const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
-          bdma16(rs_a, voff(oy + ox + cl, m), xs + (j * NW + wave) * 8 * BK);
-        }
-      } else {
-        const uint32_t toff = (uint32_t)((ky * p.win + kx) * p.cin) + cl;
-#pragma unroll
-        for (int j = 0; j < XI; ++j) {
-          const uint32_t m = 0u - ((xbits[j] >> tap) & 1u);
-          bdma16(rs_a, voff(xrow[j] + toff, m), xs + (j * NW + wave) * 8 * BK);
-        }
+      for (int j = 0; j < XI; ++j) bdma16(rs_a, xe[j], csoff, xs + (j * NW + wave) * 8 * BK);
+      ici0 += BK;
+      if (ici0 >= p.cin) {                            // scalar branch, no DMA inside
+        ici0 = 0;
+        ++itap;
+        set_tap(itap);
       }
-    } else if (k0 >= p.k1) {                          // scalar: 64 | k1
-      const uint32_t kk = kl - (uint32_t)p.k1;
+    } else if (ik0 >= p.k1) {                         // scalar; both arms issue XI DMAs
+      const uint32_t k2 = (uint32_t)(ik0 - p.k1) * 2u;
 #pragma unroll
-      for (int j = 0; j < XI; ++j) bdma16(rs_a2, voff(xrow2[j] + kk, xmask[j]), xs + (j * NW + wave) * 8 * BK);
+      for (int j = 0; j < XI; ++j) bdma16(rs_a2, xe2[j], k2, xs + (j * NW + wave) * 8 * BK);
     } else {
 #pragma unroll
-      for (int j = 0; j < XI; ++j) bdma16(rs_a, voff(xrow[j] + kl, xmask[j]), xs + (j * NW + wave) * 8 * BK);
+      for (int j = 0; j < XI; ++j) bdma16(rs_a, xe[j], ksoff, xs + (j * NW + wave) * 8 * BK);
     }
-  };
-  auto issue_any = [&](int kt, int slot) __attribute__((always_inline)) {
-    if (p.fast) issue_fast(kt, slot);
-    else issue(kt, slot);
+    ik0 += BK;
   };
 
   f32x4 acc[TN][TM];
@@ -615,7 +537,7 @@ void dd_gemm2_kernel(const GemmParams p) {
 
 #pragma unroll
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nk) issue_any(s0, s0);
+    if (s0 < nk) issue_next(s0);
 
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
@@ -628,7 +550,7 @@ void dd_gemm2_kernel(const GemmParams p) {
       else wait_vmcnt<2 * LPS>();
     }
     __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
-    if (kt + NSTAGE - 1 < nk) issue_any(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    if (kt + NSTAGE - 1 < nk) issue_next((kt + NSTAGE - 1) % NSTAGE);
     const int slot = kt % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
     const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
@@ -704,6 +626,21 @@ struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// The LDS-DMA family wants a K structure in whole 64-element steps (no step straddles a conv tap or
+// the a/a2 seam) and buffers below 2^31 bytes (32-bit lane offsets, DD_OOB out of range for all).
+bool dma_ok(const dd_gemm_desc* d) {
+  const int64_t lim = (int64_t)1 << 30;              // elements
+  const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
+  bool ok = (d->k % BK) == 0 && nw * d->k < lim;
+  if (d->conv) {
+    ok = ok && (d->cin % BK) == 0 && (int64_t)d->rows / (d->hout * d->wout) * d->hin * d->win * d->cin < lim;
+  } else {
+    ok = ok && (int64_t)d->rows * d->lda < lim;
+    if (d->a2) ok = ok && (d->k1 % BK) == 0 && (int64_t)d->rows * d->lda2 < lim;
+  }
+  return ok;
+}
+
 Plan make_plan(const dd_gemm_desc* d) {
   const bool geglu = d->epilogue == DD_EPI_GEGLU;
   Plan pl{};
@@ -724,6 +661,11 @@ Plan make_plan(const dd_gemm_desc* d) {
       if (oi == 3) ti = geglu ? 2 : 3;
     }
     if (geglu && kTiles[ti].tn % 4 != 0) ti = 2;
+  }
+  if (kTiles[ti].stages && !dma_ok(d)) {             // same tile shape, register-staged family
+    for (int i = 0; i < kNumTiles; ++i)
+      if (!kTiles[i].stages && kTiles[i].wm == kTiles[ti].wm && kTiles[i].wn == kTiles[ti].wn &&
+          kTiles[i].tm == kTiles[ti].tm && kTiles[i].tn == kTiles[ti].tn) { ti = i; break; }
   }
   const TileCfg& t = kTiles[ti];
   const int bn_out = geglu ? tile_bn(t) / 2 : tile_bn(t);
@@ -905,18 +847,6 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.scale_w = d->conv ? (float)d->win / (float)d->wv : 1.f;
   p.k_per_split = pl.k_per_split;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
-  {
-    const int64_t lim = (int64_t)1 << 31;
-    const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
-    bool fast = (d->k % BK) == 0 && nw * d->k < lim;
-    if (d->conv) {
-      fast = fast && (d->cin % BK) == 0 && (int64_t)d->rows / (d->hout * d->wout) * d->hin * d->win * d->cin < lim;
-    } else {
-      fast = fast && (int64_t)d->rows * d->lda < lim;
-      if (d->a2) fast = fast && (d->k1 % BK) == 0 && (int64_t)d->rows * d->lda2 < lim;
-    }
-    p.fast = fast ? 1 : 0;
-  }
   {
     const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
     p.w_bytes = (uint32_t)(nw * d->k * 2);

@@ -67,6 +67,30 @@ def tuned_table():
     return dict(_TUNED)
 
 
+def save_tuned(path):
+    """Persist the tuned (tile, split-K) table so a later process skips the timing sweep."""
+    import json
+    with open(path, "w") as f:
+        json.dump({"arch": "gfx950", "entries": [[repr(k), list(v)] for k, v in sorted(_TUNED.items(), key=repr)]}, f, indent=0)
+
+
+def load_tuned(path):
+    """Load a table written by save_tuned(); entries for shapes already tuned here are kept."""
+    import ast
+    import json
+    with open(path) as f:
+        blob = json.load(f)
+    if blob.get("arch") != "gfx950":
+        raise RuntimeError("tune cache %s is not for gfx950" % path)
+    n = 0
+    for k, v in blob["entries"]:
+        key = ast.literal_eval(k)
+        if key not in _TUNED:
+            _TUNED[key] = (int(v[0]), int(v[1]))
+            n += 1
+    return n
+
+
 def _autotune(lib, d, key, out_shape, dtype, device):
     hit = _TUNED.get(key)
     if hit is not None:
@@ -210,7 +234,8 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
         _TIMER.stop(e0, _kname(lib, d) + (" gemm %dx%dx%d" % (rows, n_w, k) if _TIMER.shapes else ""),
-                    2.0 * rows * n_w * k, 2.0 * (rows * k + n_w * k + rows * n))
+                    2.0 * rows * n_w * k,
+                    2.0 * (rows * k + n_w * k + rows * n * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))))
         return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
     return out
@@ -267,7 +292,8 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
         _TIMER.stop(e0, _kname(lib, d) + (" conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else ""),
-                    2.0 * rows * cout * 9 * cin, 2.0 * (x.numel() + w.numel() + rows * cout))
+                    2.0 * rows * cout * 9 * cin,
+                    2.0 * (x.numel() + w.numel() + rows * cout * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))))
         return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
     return out
