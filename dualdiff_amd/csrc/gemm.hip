@@ -554,21 +554,26 @@ void dd_gemm2_kernel(const GemmParams p) {
     const int slot = kt % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
     const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
+    // all fragment reads of the K-step go out first; the MFMAs of the first half then run while the
+    // second half's reads are still landing (counted lgkmcnt waits, reads return in order)
+    V8 wf[2][TN], xf[2][TM];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
-      V8 wf[TN], xf[TM];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+      for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
-      __builtin_amdgcn_s_setprio(1);
+      for (int j = 0; j < TM; ++j) xf[ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[i], xf[j], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
   }
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane);
 }

@@ -60,7 +60,7 @@ import os as _os
 _AUTOTUNE = _os.environ.get("DD_AUTOTUNE", "1") != "0"
 _TUNED = {}
 _TILES = None           # filled from the library (dd_gemm_tile_id) on first use
-_SPLITS = (1, 2, 4, 8, 16)
+_SPLITS = (1, 2, 3, 4, 5, 6, 8, 12, 16)
 
 
 def tuned_table():
@@ -107,26 +107,36 @@ def _autotune(lib, d, key, out_shape, dtype, device):
     global _TILES
     if _TILES is None:
         _TILES = tuple(lib.dd_gemm_tile_id(i) for i in range(lib.dd_gemm_num_tiles()))
+    def timed(tile, split, iters):
+        d.tile, d.split_k = tile, split
+        need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
+        if need > 0:
+            ws = workspace(need, device)
+            d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        if lib.dd_gemm(ctypes.byref(d), stream) != 0:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            lib.dd_gemm(ctypes.byref(d), stream)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    cands = []
     for tile in _TILES:
         for split in _SPLITS:
             if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):
                 continue
-            d.tile, d.split_k = tile, split
-            need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
-            if need > 0:
-                ws = workspace(need, device)
-                d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
-            if lib.dd_gemm(ctypes.byref(d), stream) != 0:
-                continue
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                lib.dd_gemm(ctypes.byref(d), stream)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if t < best_t:
-                best, best_t = (tile, split), t
+            t = timed(tile, split, 3)
+            if t is not None:
+                cands.append((t, tile, split))
+    # the coarse pass is noisy at the 5 % level: re-time the front-runners with more launches
+    cands.sort()
+    for t, tile, split in cands[:4]:
+        t2 = timed(tile, split, 12)
+        if t2 is not None and t2 < best_t:
+            best, best_t = (tile, split), t2
     (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
     _TUNED[key] = best
     return best

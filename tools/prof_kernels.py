@@ -22,6 +22,14 @@ if which in ("all", "conv"):
     for tile in (11, 17, 1):
         for _ in range(3):
             O.conv3x3(x, w, b, M, 28, 50, tile=tile, split_k=1)
+    x, w, b = r(M * 1400, 960), r(320, 8640, s=0.02), r(320)
+    for tile in (11, 12, 16):
+        for _ in range(3):
+            O.conv3x3(x, w, b, M, 28, 50, tile=tile, split_k=1)
+    x, w, b = r(M * 350, 1280), r(640, 11520, s=0.02), r(640)
+    for tile, sp in ((18, 1), (11, 1), (11, 3), (17, 1)):
+        for _ in range(3):
+            O.conv3x3(x, w, b, M, 14, 25, tile=tile, split_k=sp)
 if which in ("all", "gemm"):
     a, w, b = r(M * 1400, 1280), r(320, 1280, s=0.02), r(320)
     for _ in range(3):
