@@ -6,10 +6,12 @@ import bench
 from dualdiff_amd import ops as O
 from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
 
+if os.environ.get("DD_TUNE_CACHE") and os.path.exists(os.environ["DD_TUNE_CACHE"]):
+    O.load_tuned(os.environ["DD_TUNE_CACHE"])
 dtype = torch.bfloat16
 dev = torch.device("cuda:0")
 unet, cns = bench.build_models(dtype, dev)
-den = BEVDenoiser(unet, cns, use_graph=False)
+den = BEVDenoiser(unet, cns, use_graph=False, parallel_branches=False)
 with torch.no_grad():
     den.set_inputs(*bench.synthetic_inputs(1, dtype, dev, 1))
     den.step(0); den.step(1)
