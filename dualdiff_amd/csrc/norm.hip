@@ -192,6 +192,142 @@ void dd_gn_apply_kernel(const GnParams p) {
   }
 }
 
+// ---- single-launch GroupNorm for slabs that fit the register file --------------------------------
+// One block owns (instance, `cpb` channels = whole groups) and keeps its hw x cpb slab in registers
+// (<= NVMAX 16-B vectors per thread): one HBM read, statistics through a fixed-order LDS reduction
+// (bit-reproducible), normalise + SiLU + store.  Used from the 14x25 level
+// down, where the two-launch path is pure launch + latency; 1024-thread blocks for the larger slabs
+// so that the per-thread VALU chain stays short.
+template <typename T, int THREADS, int NVMAX>
+__global__ __launch_bounds__(THREADS)
+void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int kred) {
+  __shared__ float s_a0[THREADS], s_a1[THREADS], s_q0[THREADS], s_q1[THREADS];
+  __shared__ float s_mean[64], s_rstd[64];
+  const int inst = blockIdx.y;
+  const int t = threadIdx.x;
+  const bool active = t < vpp * plc;
+  const int cv = t % vpp, pl = t / vpp;
+  const int gpb = cpb / p.cpg;
+  const int lch = cv * 8;                               // channel inside the block
+  const int g0 = lch / p.cpg;                           // local group of the vector's first channel
+  const int g1 = min(g0 + 1, gpb - 1);
+  const int nfirst = min(8, (g0 + 1) * p.cpg - lch);    // channels of the vector that belong to g0
+  // every lane loads (clamped address) so all nv loads are in flight at once; lanes / pixels
+  // outside the slab are masked out of the statistics and never stored
+  const int ch = blockIdx.x * cpb + min(cv, vpp - 1) * 8;
+  u32x4 raw[NVMAX];
+#pragma unroll
+  for (int i = 0; i < NVMAX; ++i)
+    if (i < nv) raw[i] = dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + min(pl + i * plc, p.hw - 1), ch));
+  const u32x4 graw = dd_ld16(reinterpret_cast<const T*>(p.gamma) + ch);
+  const u32x4 braw = dd_ld16(reinterpret_cast<const T*>(p.beta) + ch);
+  const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
+
+  // statistics in one pass (sum, sum of squares — the arithmetic of the two-launch path), reduced in
+  // a fixed order (2 barriers, bit-reproducible).
+  float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVMAX; ++i) {
+    if (i < nv) {
+      float f[8];
+      dd_unpack8<T>(raw[i], f);
+      const float keep = pl + i * plc < p.hw ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = keep * f[e];
+        if (e < nfirst) { a0 += v; q0 += v * v; } else { a1 += v; q1 += v * v; }
+      }
+    }
+  }
+  s_a0[t] = active ? a0 : 0.f; s_a1[t] = active ? a1 : 0.f;
+  s_q0[t] = active ? q0 : 0.f; s_q1[t] = active ? q1 : 0.f;
+  __syncthreads();
+  {
+    // one wave per group: lanes stride over the (pixel lane, channel vector) shares that can touch
+    // the group, then a fixed-order wave reduction
+    const int wave = t >> 6, lane = t & 63;
+    for (int g = wave; g < gpb; g += THREADS / 64) {
+      const int lo = (g * p.cpg) >> 3, hi = ((g + 1) * p.cpg - 1) >> 3;
+      const int nvec = hi - lo + 1;
+      const int n = plc * nvec;
+      float sum = 0.f, sq = 0.f;
+      for (int idx = lane; idx < n; idx += 64) {
+        const int l = idx / nvec;
+        const int c = lo + (idx - l * nvec);
+        const int src = l * vpp + c;
+        const int cg0 = (c * 8) / p.cpg;
+        if (cg0 == g) { sum += s_a0[src]; sq += s_q0[src]; }
+        else if (cg0 + 1 == g) { sum += s_a1[src]; sq += s_q1[src]; }
+      }
+      sum = dd_wave_sum(sum);
+      sq = dd_wave_sum(sq);
+      if (lane == 0) {
+        const float mean = sum * inv_n;
+        s_mean[g] = mean;
+        s_rstd[g] = rsqrtf(fmaxf(sq * inv_n - mean * mean, 0.f) + p.eps);
+      }
+    }
+  }
+  __syncthreads();
+  const float mean0 = s_mean[g0], mean1 = s_mean[g1];
+  const float rstd0 = s_rstd[g0], rstd1 = s_rstd[g1];
+  if (!active) return;
+  float ga[8], be[8], sc[8], sh[8];
+  dd_unpack8<T>(graw, ga);
+  dd_unpack8<T>(braw, be);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float mu = e < nfirst ? mean0 : mean1, rs = e < nfirst ? rstd0 : rstd1;
+    sc[e] = rs * ga[e];
+    sh[e] = be[e] - mu * sc[e];
+  }
+#pragma unroll
+  for (int i = 0; i < NVMAX; ++i) {
+    const int px = pl + i * plc;
+    if (i < nv && px < p.hw) {
+      float f[8];
+      dd_unpack8<T>(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = f[e] * sc[e] + sh[e];
+        f[e] = p.silu ? dd_silu_f(y) : y;
+      }
+      dd_st16(reinterpret_cast<T*>(p.y) + ((int64_t)inst * p.hw + px) * p.c + ch, dd_pack8<T>(f));
+    }
+  }
+}
+
+constexpr int GNF_NV_SMALL = 8;      // 256-thread blocks
+constexpr int GNF_NV_BIG = 4;        // 1024-thread blocks (<= 128 VGPRs)
+
+// picks channels-per-block (whole groups, a multiple of 8, >= 40 channels) and the block size so
+// that a block's slab fits the register budget; false -> use the two-launch path
+bool gn_fused_plan(int hw, int c, int groups, int* cpb, int* vpp, int* plc, int* nv, int* kred, int* threads) {
+  const int cpg = c / groups;
+  for (int gpb = 1; gpb <= groups && gpb <= 64; ++gpb) {
+    if (groups % gpb) continue;
+    const int cb = cpg * gpb;
+    if (cb % 8 || cb < 40) continue;
+    const int v = cb / 8;
+    // 256-thread blocks while the slab needs <= 4 vectors per thread, else 1024 threads (short
+    // per-thread chain), else 256 threads up to the register budget
+    const int try_th[3] = {256, 1024, 256};
+    const int try_cap[3] = {4, GNF_NV_BIG, GNF_NV_SMALL};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int th = try_th[pass];
+      if (v > th) continue;
+      int pl = th / v;
+      if (pl > hw) pl = hw;
+      const int n = (hw + pl - 1) / pl;
+      if (n > try_cap[pass]) continue;
+      *cpb = cb; *vpp = v; *plc = pl; *nv = n; *kred = 0; *threads = th;
+      return true;
+    }
+    return false;          // the smallest legal channel chunk does not fit: larger ones will not either
+  }
+  return false;
+}
+
 // ---- LayerNorm: one wave per row, row held in registers, two-pass (mean, centred var) ----
 constexpr int LN_MAXV = 4;   // up to 4 x (64 lanes x 8) = 2048 channels
 
@@ -240,6 +376,73 @@ void dd_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
   }
 }
 
+// LayerNorm for c = 40 * LPR (320 / 640 / 1280, the widths of this network): LPR lanes share a row,
+// five 16-B vectors per lane, so a wave normalises 64 / LPR rows with all its loads in flight at
+// once and a log2(LPR)-step reduction.  Same two-pass arithmetic as the generic kernel.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256)
+void dd_layernorm_sub_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                             const T* __restrict__ beta, T* __restrict__ y,
+                             int64_t rows, float eps) {
+  constexpr int VPL = 5;
+  constexpr int C = LPR * VPL * 8;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool ok = row < rows;
+  const int64_t r = ok ? row : rows - 1;             // keep every lane in the shuffles
+  u32x4 raw[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) raw[i] = dd_ld16(x + r * C + (sub + i * LPR) * 8);
+  float f[VPL][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    dd_unpack8<T>(raw[i], f[i]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += f[i][e];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s * (1.0f / (float)C);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; ss += d * d; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rstd = rsqrtf(ss * (1.0f / (float)C) + eps);
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = sub + i * LPR;
+    float ga[8], be[8], o[8];
+    dd_unpack8<T>(dd_ld16(gamma + v * 8), ga);
+    dd_unpack8<T>(dd_ld16(beta + v * 8), be);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * ga[e] + be[e];
+    dd_st16(y + row * C + v * 8, dd_pack8<T>(o));
+  }
+}
+
+template <typename T>
+bool launch_layernorm_sub(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int c,
+                          float eps, hipStream_t s) {
+  auto go = [&](auto kern, int lpr) {
+    const int rpb = 4 * (64 / lpr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s,
+                       (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, rows, eps);
+  };
+  switch (c) {
+    case 320: go(dd_layernorm_sub_kernel<T, 8>, 8); return true;
+    case 640: go(dd_layernorm_sub_kernel<T, 16>, 16); return true;
+    case 1280: go(dd_layernorm_sub_kernel<T, 32>, 32); return true;
+    default: return false;
+  }
+}
+
 int gn_plan(int hw, int c, int* pix_per_split) {
   // enough blocks to fill the chip, but at least a few pixels per pixel-lane
   const int cv = c / 8;
@@ -282,6 +485,18 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
   p.nsplit = gn_plan(hw, c, &p.pix_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();
+  int cpb, vpp, plc, nv, kred, threads;
+  if (gn_fused_plan(hw, c, groups, &cpb, &vpp, &plc, &nv, &kred, &threads)) {
+    dim3 fgrid(c / cpb, m);
+    if (threads == 256) {
+      if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_fused_kernel<_Float16, 256, GNF_NV_SMALL>), fgrid, dim3(256), 0, s, p, cpb, vpp, plc, nv, kred);
+      else hipLaunchKernelGGL((dd_gn_fused_kernel<__bf16, 256, GNF_NV_SMALL>), fgrid, dim3(256), 0, s, p, cpb, vpp, plc, nv, kred);
+    } else {
+      if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_fused_kernel<_Float16, 1024, GNF_NV_BIG>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
+      else hipLaunchKernelGGL((dd_gn_fused_kernel<__bf16, 1024, GNF_NV_BIG>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
+    }
+    return dd_check_launch();
+  }
   dim3 grid(p.nsplit, m);
   if (dtype == DD_F16) {
     hipLaunchKernelGGL(dd_gn_stats_kernel<_Float16>, grid, dim3(GN_THREADS), 0, s, p);
@@ -302,6 +517,9 @@ extern "C" int dd_layernorm(const void* x, const void* gamma, const void* beta, 
   if (!dd_aligned16(x) || !dd_aligned16(y) || !dd_aligned16(gamma) || !dd_aligned16(beta)) return DD_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();
+  if (dtype == DD_F16 ? launch_layernorm_sub<_Float16>(x, gamma, beta, y, rows, c, eps, s)
+                      : launch_layernorm_sub<__bf16>(x, gamma, beta, y, rows, c, eps, s))
+    return dd_check_launch();
   const unsigned blocks = (unsigned)((rows + 3) / 4);
   if (dtype == DD_F16) {
     hipLaunchKernelGGL(dd_layernorm_kernel<_Float16>, dim3(blocks), dim3(256), 0, s,

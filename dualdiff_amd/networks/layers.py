@@ -321,6 +321,12 @@ class Attention(_Cached):
     def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None):
         c = self.inner_dim
         q = self.to_q.run(x2d)
+        pre = self.__dict__.pop("_kv_prefetched", None)
+        if kv is None and pre is not None and pre[0] is ctx2d:
+            kv, side = pre[1], pre[2]                # projected ahead of time on a side stream
+            torch.cuda.current_stream().wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():     # graph pools keep the block alive themselves
+                kv.record_stream(torch.cuda.current_stream())
         if kv is None:
             kv = self.project_kv(ctx2d)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale)
@@ -329,6 +335,28 @@ class Attention(_Cached):
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                               attention_mask=attention_mask, **kw)
+
+
+def prefetch_cross_kv(model, ctx2d, side):
+    """Projects K/V of every built-in cross-attention layer of `model` for the context `ctx2d` on the
+    stream `side`.  The context (text / camera / box tokens) does not depend on the latents, so these
+    GEMMs leave the serial chain of the step and fill CUs the chain leaves idle; the first layer that
+    needs them joins the side stream.  Same kernels, same inputs -> same bits."""
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for blk in model.modules():
+            mod = getattr(blk, "attn2", None) if isinstance(blk, BasicTransformerBlock) else None
+            if mod is not None and mod.is_cross and isinstance(mod.processor, HIPAttnProcessor):
+                mod.__dict__["_kv_prefetched"] = (ctx2d, mod.project_kv(ctx2d), side)
+
+
+def drop_prefetched_kv(model, side):
+    """Joins `side` back and forgets any K/V no layer consumed (keeps graph capture well-formed)."""
+    torch.cuda.current_stream().wait_stream(side)
+    for mod in model.modules():
+        if isinstance(mod, Attention):
+            mod.__dict__.pop("_kv_prefetched", None)
 
 
 class GEGLU(nn.Module):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import ops as O
 from .blocks import BasicMultiviewTransformerBlock
-from .layers import (Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
+from .layers import (prefetch_cross_kv, drop_prefetched_kv, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
                      TimestepEmbedding, Timesteps, UNetMidBlock2DCrossAttn, UpBlock2D, as_nchw_view,
                      run_down_block, run_up_block, to_nhwc)
 from .model_base import ModelBase
@@ -33,6 +33,11 @@ _DEFAULT_PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0
 
 
 class UNet2DConditionModelMultiview(ModelBase):
+    # Side-stream projection of the cross-attention K/V (layers.prefetch_cross_kv).  Measured on MI355X
+    # (config 2, graph replay): 66.0 steps/s off vs 62.4 on — the extra stream's small GEMMs delay the
+    # main chain more than they shorten it — so it is off; DD_PREFETCH_KV=1 turns it on.
+    prefetch_kv = __import__('os').environ.get('DD_PREFETCH_KV', '0') == '1'
+
     _WARN_ONCE = 0
 
     def __init__(
@@ -228,6 +233,10 @@ class UNet2DConditionModelMultiview(ModelBase):
         """conv_in + down path + mid block — everything that does NOT depend on the ControlNet
         residuals, so a sampler can overlap it with the ControlNet branches on other streams."""
         dt = self.dtype
+        if self.prefetch_kv:
+            if self.__dict__.get("_kv_stream") is None:
+                self.__dict__["_kv_stream"] = torch.cuda.Stream()
+            prefetch_cross_kv(self, ctx2d, self.__dict__["_kv_stream"])
         # 1. time (unet_2d_condition_multiview.py:404-411)
         emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
         temb = self.temb_bank.run(O.silu(emb))
@@ -271,4 +280,6 @@ class UNet2DConditionModelMultiview(ModelBase):
             x, h, w = run_up_block(blk, x, m, h, w, skips, temb, ctx2d, lc, up_size)
         # 6. post-process (:519-522): GN + SiLU fused, conv_out writes NCHW directly
         a = self.conv_norm_out.run(x, m, h * w, True)
+        if self.__dict__.get("_kv_stream") is not None:
+            drop_prefetched_kv(self, self.__dict__["_kv_stream"])
         return O.conv3x3_small_cout(a, self.conv_out.packed, self.conv_out.bias, m, h, w)

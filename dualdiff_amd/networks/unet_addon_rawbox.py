@@ -26,7 +26,7 @@ from .. import ops as O
 from ..misc.common import load_module
 from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor  # noqa: F401
 from .embedder import get_embedder
-from .layers import (Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
+from .layers import (prefetch_cross_kv, drop_prefetched_kv, Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
                      UNetMidBlock2DCrossAttn, as_nchw_view, run_down_block, to_nhwc)
 from .model_base import ModelBase
 from .output_cls import BEVControlNetOutput
@@ -52,6 +52,11 @@ class _AdmProj(nn.Module):
 
 
 class BEVControlNetModel(ModelBase):
+    # Side-stream K/V projection (layers.prefetch_cross_kv) is OFF by default for the ControlNet: the
+    # sampler runs each branch on a forked stream, and ROCm 7.2's hipStreamEndCapture crashes when a
+    # forked stream forks again (tools/capture_topology.py reproduces it); only the UNet, which runs on
+    # the capture's origin stream, prefetches.
+    prefetch_kv = False
     _keys_to_ignore_on_load_missing = ("adm_proj", "txt_con_fusion", "txt_con_fusionp")
 
     def __init__(
@@ -290,15 +295,21 @@ class BEVControlNetModel(ModelBase):
         place — the dual-branch sum of pipeline_bev_controlnet.py:421-429 without extra passes."""
         dt = self.dtype
         assert not self.use_cam_in_temb, "not available now (:954)"
+        ctx2d, lc = prep["ctx2d"], prep["lc"]
+        if self.prefetch_kv:
+            if self.__dict__.get("_kv_stream") is None:
+                self.__dict__["_kv_stream"] = torch.cuda.Stream()
+            prefetch_cross_kv(self, ctx2d, self.__dict__["_kv_stream"])
         emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
         temb = self.temb_bank.run(O.silu(emb))
-        ctx2d, lc = prep["ctx2d"], prep["lc"]
         x = self.conv_in.run(x, m, h, w, res=prep["cond"])              # conv_in + `sample += cond` (:965,:990)
         skips = [(x, h, w)]
         for blk in self.down_blocks:
             x, h, w, s = run_down_block(blk, x, m, h, w, temb, ctx2d, lc)
             skips += s
         x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc)
+        if self.__dict__.get("_kv_stream") is not None:
+            drop_prefetched_kv(self, self.__dict__["_kv_stream"])
         outs = []
         for i, ((s, sh, sw), zc) in enumerate(zip(skips, self.controlnet_down_blocks)):       # :1031-1054
             dst = out[i][0] if out is not None else None
