@@ -374,7 +374,8 @@ void dd_gemm2_kernel(const GemmParams p) {
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
   static_assert(NW % 2 == 0, "swizzle must not depend on the instruction index");
   static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "NSTAGE");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 8, "NSTAGE");
+  static_assert((NSTAGE - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);
@@ -544,10 +545,14 @@ void dd_gemm2_kernel(const GemmParams p) {
     if (NSTAGE == 2) {
       wait_vmcnt<0>();
     } else {
-      const int ahead = min(nk - 1 - kt, NSTAGE - 2);
-      if (ahead == 0) wait_vmcnt<0>();
-      else if (ahead == 1) wait_vmcnt<LPS>();
-      else wait_vmcnt<2 * LPS>();
+      const int ahead = min(nk - 1 - kt, NSTAGE - 2);     // scalar; stages allowed to stay in flight
+      if (ahead <= 0) wait_vmcnt<0>();
+      else if (ahead == 1 || NSTAGE <= 3) wait_vmcnt<(NSTAGE > 2 ? 1 : 0) * LPS>();
+      else if (ahead == 2 || NSTAGE <= 4) wait_vmcnt<(NSTAGE > 3 ? 2 : 0) * LPS>();
+      else if (ahead == 3 || NSTAGE <= 5) wait_vmcnt<(NSTAGE > 4 ? 3 : 0) * LPS>();
+      else if (ahead == 4 || NSTAGE <= 6) wait_vmcnt<(NSTAGE > 5 ? 4 : 0) * LPS>();
+      else if (ahead == 5 || NSTAGE <= 7) wait_vmcnt<(NSTAGE > 6 ? 5 : 0) * LPS>();
+      else wait_vmcnt<(NSTAGE > 7 ? 6 : 0) * LPS>();
     }
     __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
     if (kt + NSTAGE - 1 < nk) issue_next((kt + NSTAGE - 1) % NSTAGE);
@@ -619,6 +624,12 @@ constexpr TileCfg kTiles[] = {
     {18, 2, 2, 2, 2, 2, "64x64/dma2"},
     {19, 2, 2, 2, 2, 4, "64x64/dma4"},
     {20, 4, 2, 4, 4, 3, "256x128/dma3"},
+    // deep rings for cold-weight streaming (few rows, long K): most of a block's K range in flight
+    {21, 2, 2, 2, 2, 6, "64x64/dma6"},
+    {22, 2, 2, 2, 2, 8, "64x64/dma8"},
+    {23, 2, 2, 4, 2, 4, "128x64/dma4"},
+    {24, 2, 2, 2, 4, 4, "64x128/dma4"},
+    {25, 2, 2, 4, 4, 4, "128x128/dma4"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -743,6 +754,11 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 17: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 2, CONV, false>(p, pl, s); break;
     case 18: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 2, CONV, false>(p, pl, s); break;
     case 19: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 4, CONV, false>(p, pl, s); break;
+    case 21: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 6, CONV, false>(p, pl, s); break;
+    case 22: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 8, CONV, false>(p, pl, s); break;
+    case 23: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 4, CONV, false>(p, pl, s); break;
+    case 24: return launch_cfg2<T, 2, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
+    case 25: return launch_cfg2<T, 2, 2, 4, 4, 4, CONV, GEGLU>(p, pl, s);
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
