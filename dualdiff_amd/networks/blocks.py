@@ -38,6 +38,22 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         self.connector = Linear(dim, dim)
         self._maps = {}
 
+    # `connector(to_out(o))` is two Linear layers with nothing in between (blocks.py:203-222): they
+    # run as ONE GEMM with W = Wc Wo and b = Wc (nb b_o) + b_c, folded in fp32 when the weights change.
+    fold_connector = True
+
+    def _folded_out(self, nb):
+        wo, bo = self.attn4.to_out[0].weight, self.attn4.to_out[0].bias
+        wc, bc = self.connector.weight, self.connector.bias
+        key = (nb, wo._version, bo._version, wc._version, bc._version, wo.data_ptr(), wc.data_ptr())
+        hit = self.connector.__dict__.get("_pk_fold")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w = (wc.detach().float() @ wo.detach().float()).to(wo.dtype).contiguous()
+                b = (wc.detach().float() @ (bo.detach().float() * nb) + bc.detach().float()).to(wo.dtype).contiguous()
+            hit = self.connector.__dict__["_pk_fold"] = (key, w, b)
+        return hit[1], hit[2]
+
     @property
     def n_cam(self):
         return len(self.neighboring_view_pair)
@@ -73,9 +89,13 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, l, l, a.heads, a.dim_head,
                             a.scale, kv_batch_map=mp, out=o, accumulate=j > 0)
         nb = len(maps)
-        if "_pk_bias_nb" not in a.__dict__ or a.__dict__["_pk_bias_nb"][0] != nb:
-            a.__dict__["_pk_bias_nb"] = (nb, (a.to_out[0].bias.detach().float() * nb).to(a.to_out[0].bias.dtype))
-        y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
-        h = self.connector.run(y, res=h)
+        if self.fold_connector:
+            w, b = self._folded_out(nb)
+            h = O.gemm(o, w, b, res=h)
+        else:
+            if "_pk_bias_nb" not in a.__dict__ or a.__dict__["_pk_bias_nb"][0] != nb:
+                a.__dict__["_pk_bias_nb"] = (nb, (a.to_out[0].bias.detach().float() * nb).to(a.to_out[0].bias.dtype))
+            y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
+            h = self.connector.run(y, res=h)
         # ---- feed-forward ------------------------------------------------------------------
         return self.ff.run(self.norm3.run(h), res=h)
