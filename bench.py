@@ -134,19 +134,50 @@ def _metric_name():
         return "denoising-steps/sec, 6-view 224x400, 50-step DDIM"
 
 
+def _mangled_fragment(kernel):
+    """'dd_gemm2_kernel<__bf16, 2, 2, 4, 4, 2, true, false>' -> 'dd_gemm2_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1ELb0EE'
+    (rocprofv3 prints most of our symbols mangled); 'dd_attn_kernel<bf16,D40>' -> 'dd_attn_kernelIDF16bLi40E'."""
+    import re
+    m = re.match(r"(\w+)<(.*)>", kernel)
+    if not m:
+        return kernel
+    name, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    out = name + "I"
+    closed = True
+    for a in args:
+        if a in ("__bf16", "bf16"):
+            out += "DF16b"
+        elif a in ("_Float16", "f16"):
+            out += "DF16_"
+        elif a in ("true", "false"):
+            out += "Lb%dE" % (a == "true")
+        elif re.fullmatch(r"-?\d+", a):
+            out += "Li%sE" % a
+        elif re.fullmatch(r"D\d+", a):          # our attention label carries only dtype and head dim
+            out += "Li%sE" % a[1:]
+            closed = False
+        else:
+            return kernel
+    return out + ("E" if closed else "")
+
+
 def _pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 +
-    WRITE_SIZE, separate passes, see tools/pmc_summary.py); None when the profile has no such kernel."""
+    WRITE_SIZE, separate passes, tools/pmc_summary.py + tools/refresh_profiles.sh); None when the
+    profile has no such kernel.  Several instantiations matching the label are launch-weighted."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
+    frag = _mangled_fragment(kernel)
+    tot = n = 0.0
     for name, row in table.items():
-        if kernel in name:
-            return row["hbm_bytes_per_launch"]
-    return None
+        if frag in name or kernel in name:
+            tot += row["hbm_bytes_per_launch"] * row["launches_fetch_pass"]
+            n += row["launches_fetch_pass"]
+    return tot / n if n else None
 
 
 def main():

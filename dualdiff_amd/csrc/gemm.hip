@@ -88,20 +88,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ---- accumulator tile -> global (shared by both kernel families) ---------------------------
 // acc[tn][tm][reg]: output row = tile row tm*16 + (lane & 15),
 //                   output col = q*(4*TN) + tn*4 + reg  (q = lane >> 4)   [non-GEGLU]
+// Every global read of the epilogue (bias, time-embedding vector, residual, accumulate target) is
+// issued BEFORE the first store: `out` may alias `res`, so a load placed after a store could not be
+// hoisted by the compiler and the tile would pay one memory round trip per 8-column group.
 template <typename T, int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
                                            int block_n0, int wave_m, int wave_n, int lane) {
   const int q = lane >> 4;
   const int c = lane & 15;
+  const int row0 = block_m0 + wave_m * (TM * 16) + c;
+  if constexpr (GEGLU) {
+    constexpr int TH = TN / 2;
+    constexpr int NG = TH / 2;
+    const int col0 = block_n0 + wave_n * (TH * 16) + q * (4 * TH);
+    u32x4 bh[NG], bg[NG];
+    if (p.bias) {
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int row = block_m0 + wave_m * (TM * 16) + tm * 16 + c;
-    if (row >= p.rows) continue;
-    if (GEGLU) {
-      constexpr int TH = TN / 2;
-      const int col0 = block_n0 + wave_n * (TH * 16) + q * (4 * TH);
+      for (int g8 = 0; g8 < NG; ++g8) {
+        const int col = min(col0 + g8 * 8, p.n - 8);
+        bh[g8] = dd_ld16(reinterpret_cast<const T*>(p.bias) + col);
+        bg[g8] = dd_ld16(reinterpret_cast<const T*>(p.bias) + p.n + col);
+      }
+    }
 #pragma unroll
-      for (int g8 = 0; g8 < TH / 2; ++g8) {
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = row0 + tm * 16;
+      if (row >= p.rows) continue;
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
         const int col = col0 + g8 * 8;
         if (col >= p.n) continue;
         float h[8], g[8];
@@ -112,10 +126,10 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         }
         if (p.bias) {
           float b[8];
-          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + col), b);
+          dd_unpack8<T>(bh[g8], b);
 #pragma unroll
           for (int e = 0; e < 8; ++e) h[e] += b[e];
-          dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + p.n + col), b);
+          dd_unpack8<T>(bg[g8], b);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] += b[e];
         }
@@ -124,22 +138,94 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         for (int e = 0; e < 8; ++e) v[e] = h[e] * dd_gelu_erf_f(g[e]);
         dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
       }
-    } else {
-      const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
+    }
+  } else {
+    constexpr int NG = TN / 2;
+    const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
+    if (p.partial) {                       // split-K slab: plain fp32 stores, the reduce kernel runs the epilogue
 #pragma unroll
-      for (int g8 = 0; g8 < TN / 2; ++g8) {
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = row0 + tm * 16;
+        if (row >= p.rows) continue;
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8) {
+          const int col = col0 + g8 * 8;
+          if (col >= p.n) continue;
+          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
+          *reinterpret_cast<f32x4*>(dst) = acc[g8 * 2][tm];
+          *reinterpret_cast<f32x4*>(dst + 4) = acc[g8 * 2 + 1][tm];
+        }
+      }
+      return;
+    }
+    // ---- phase 1: all loads (clamped addresses: every lane loads, nothing is predicated) ----
+    u32x4 rb[NG], rv[TM][NG], rr[TM][NG], ra[TM][NG];
+    int colc[NG];
+#pragma unroll
+    for (int g8 = 0; g8 < NG; ++g8) colc[g8] = min(col0 + g8 * 8, p.n - 8);
+    if (p.bias) {
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) rb[g8] = dd_ld16(reinterpret_cast<const T*>(p.bias) + colc[g8]);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int rowc = min(row0 + tm * 16, p.rows - 1);
+      if (p.rowvec) {
+        const int inst = rowc / p.rows_per_inst;
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8)
+          rv[tm][g8] = dd_ld16(reinterpret_cast<const T*>(p.rowvec) + (int64_t)inst * p.ld_rowvec + colc[g8]);
+      }
+      if (p.res) {
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8)
+          rr[tm][g8] = dd_ld16(reinterpret_cast<const T*>(p.res) + (int64_t)rowc * p.ldres + colc[g8]);
+      }
+      if (p.accumulate) {
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8)
+          ra[tm][g8] = dd_ld16(reinterpret_cast<const T*>(p.out) + (int64_t)rowc * p.ldc + colc[g8]);
+      }
+    }
+    // ---- phase 2: arithmetic in the reference's order (bias, time vector, alpha, residual, act, accumulate) + stores ----
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = row0 + tm * 16;
+      if (row >= p.rows) continue;
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
         const int col = col0 + g8 * 8;
         if (col >= p.n) continue;
-        float v[8];
+        float v[8], b[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
-        if (p.partial) {
-          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
-          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-          epilogue_store8<T>(p, row, col, v);
+        if (p.bias) {
+          dd_unpack8<T>(rb[g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
         }
+        if (p.rowvec) {
+          dd_unpack8<T>(rv[tm][g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        if (p.res) {
+          dd_unpack8<T>(rr[tm][g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+        if (p.act == DD_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = dd_silu_f(v[e]);
+        }
+        if (p.accumulate) {
+          dd_unpack8<T>(ra[tm][g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+        dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
       }
     }
   }
@@ -630,6 +716,9 @@ constexpr TileCfg kTiles[] = {
     {23, 2, 2, 4, 2, 4, "128x64/dma4"},
     {24, 2, 2, 2, 4, 4, "64x128/dma4"},
     {25, 2, 2, 4, 4, 4, "128x128/dma4"},
+    // tall tiles for the 4x7 / 7x13 levels (336 / 1092 rows x 1280 x up to 23040): all (or a third of)
+    // the rows in one tile so the 29-59 MB weight matrix is streamed once, not once per 128 rows
+    {26, 4, 2, 6, 2, 2, "384x64/dma2"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -679,9 +768,11 @@ Plan make_plan(const dd_gemm_desc* d) {
     if (geglu && kTiles[ti].tn % 4 != 0) ti = 2;
   }
   if (kTiles[ti].stages && !dma_ok(d)) {             // same tile shape, register-staged family
+    int alt = geglu ? 0 : 3;                          // no twin: 128x128 (GEGLU-capable) / 64x64
     for (int i = 0; i < kNumTiles; ++i)
       if (!kTiles[i].stages && kTiles[i].wm == kTiles[ti].wm && kTiles[i].wn == kTiles[ti].wn &&
-          kTiles[i].tm == kTiles[ti].tm && kTiles[i].tn == kTiles[ti].tn) { ti = i; break; }
+          kTiles[i].tm == kTiles[ti].tm && kTiles[i].tn == kTiles[ti].tn) { alt = i; break; }
+    ti = alt;
   }
   const TileCfg& t = kTiles[ti];
   const int bn_out = geglu ? tile_bn(t) / 2 : tile_bn(t);
@@ -759,6 +850,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 23: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 4, CONV, false>(p, pl, s); break;
     case 24: return launch_cfg2<T, 2, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 25: return launch_cfg2<T, 2, 2, 4, 4, 4, CONV, GEGLU>(p, pl, s);
+    case 26: if constexpr (!GEGLU) return launch_cfg2<T, 4, 2, 6, 2, 2, CONV, false>(p, pl, s); break;
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
