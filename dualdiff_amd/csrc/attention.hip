@@ -29,6 +29,7 @@ struct AttnParams {
   float scale_log2;
   const int32_t* kv_map;
   int accumulate;
+  int nqb;             // q-blocks per (batch, head), filled by the launcher
 };
 
 
@@ -65,11 +66,20 @@ void dd_attn_kernel(const AttnParams p) {
   const int g = lane >> 4;        // lane group 0..3
   const int c = lane & 15;
 
-  const int bh = blockIdx.y;
+  // XCD-aware order: workgroups i, i+8, ... share an XCD (and its L2); give each XCD a contiguous
+  // run of (batch*head, q-block) items so all q-blocks of a head read that head's K/V through ONE L2
+  // (a plain 2-D grid spreads them over the 8 XCDs: K/V were fetched 8x, rocprofv3 FETCH_SIZE).
+  const int nqb = p.nqb;
+  const int nwg = nqb * p.batch * p.heads;
+  const int xcd = blockIdx.x & 7;
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int item = ((xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int bh = item / nqb;
+  const int qb = item - bh * nqb;
   const int b = bh / p.heads;
   const int h = bh - b * p.heads;
   const int kb = p.kv_map ? p.kv_map[b] : b;
-  const int q0 = (blockIdx.x * 4 + wave) * (QT * 16);
+  const int q0 = (qb * 4 + wave) * (QT * 16);
 
   const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * D;
   const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * D;
@@ -287,8 +297,10 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
   constexpr int DVT = (D + 15) / 16;
   constexpr size_t smem = (size_t)KV_TILE * ((DQ + 16) + (DVT * 16 + (D == 160 ? 16 : 0))) * sizeof(T);
   const int qblk = 4 * QT * 16;
-  dim3 grid((p.lq + qblk - 1) / qblk, p.batch * p.heads);
-  hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR, KV_TILE>), grid, dim3(256), smem, s, p);
+  AttnParams pp = p;
+  pp.nqb = (p.lq + qblk - 1) / qblk;
+  dim3 grid(pp.nqb * p.batch * p.heads);
+  hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR, KV_TILE>), grid, dim3(256), smem, s, pp);
   return dd_check_launch();
 }
 
