@@ -252,10 +252,14 @@ class BEVControlNetModel(ModelBase):
                           use_aug_text=False):
         """Step-invariant half of forward() (:831-896, :967-988).  Returns a dict with
         `ctx2d` ((b n)*(78+N), 768), `lc`, `cond` ((b n)*h*w, 320) NHWC, `m`, `h`, `w`."""
+        tok = self.prepare_tokens(camera_param, bboxes_3d_data, encoder_hidden_states, use_aug_text)
+        return self.prepare_cond(tok, controlnet_cond)
+
+    def prepare_tokens(self, camera_param, bboxes_3d_data, encoder_hidden_states, use_aug_text=False):
+        """Token half (:831-896, :1007): camera / text / box tokens -> `ctx`, `ctx2d`, `lc`, `m`.
+        The UNet only needs these, so a sampler can start it before the condition image is embedded."""
         self.use_aug_text = use_aug_text
         dt = self.dtype
-        if self.config.controlnet_conditioning_channel_order == "bgr":
-            controlnet_cond = torch.flip(controlnet_cond, dims=[1])
         b, n_cam = camera_param.shape[:2]
         ctx = self.add_cam_states(encoder_hidden_states, self._embed_camera(camera_param))    # b, n, L+1, 768
         box = None
@@ -271,6 +275,17 @@ class BEVControlNetModel(ModelBase):
                 box = box.expand(-1, n_cam, -1, -1)
         m = b * n_cam
         ctx = ctx.reshape(m, ctx.shape[2], ctx.shape[3])
+        full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1007
+        full = full.contiguous()
+        return {"ctx": full, "ctx2d": full.reshape(-1, full.shape[-1]), "lc": full.shape[1], "m": m,
+                "txt": ctx[:, 1:].contiguous()}                     # text tokens without the camera token (:977)
+
+    def prepare_cond(self, tok, controlnet_cond):
+        """Condition-image half (:967-988): embed the ORS condition (or take the ORS-3D volume), SFA."""
+        dt = self.dtype
+        m = tok["m"]
+        if self.config.controlnet_conditioning_channel_order == "bgr":
+            controlnet_cond = torch.flip(controlnet_cond, dims=[1])
         if not self.use_occ_3d:
             cond, mc, h, w = self.controlnet_cond_embedding.run(controlnet_cond)
         else:
@@ -280,14 +295,13 @@ class BEVControlNetModel(ModelBase):
         assert not (self.use_txt_con_fusion and self.use_txt_con_fusionp)
         if self.use_txt_con_fusion or self.use_txt_con_fusionp:
             sfa = self.txt_con_fusion if self.use_txt_con_fusion else self.txt_con_fusionp
-            txt = ctx[:, 1:].contiguous()                               # without the camera token (:977)
+            txt = tok["txt"]
             cond = sfa.run(cond, m, h * w, txt.reshape(-1, txt.shape[-1]), txt.shape[1])
         else:
             assert self.txt_con_fusion is None or not self.use_txt_con_fusion
-        full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1007
-        full = full.contiguous()
-        return {"ctx": full, "ctx2d": full.reshape(-1, full.shape[-1]), "lc": full.shape[1],
-                "cond": cond, "m": m, "h": h, "w": w}
+        out = dict(tok)
+        out.update({"cond": cond, "h": h, "w": w})
+        return out
 
     def forward_nhwc(self, x, m, h, w, t_f32, prep, conditioning_scale=1.0, out=None, accumulate=False):
         """x: (m*h*w, 8) padded NHWC latents; returns [12 down residuals] + [mid] as NHWC 2-D tensors

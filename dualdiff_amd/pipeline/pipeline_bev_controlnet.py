@@ -120,23 +120,27 @@ class BEVDenoiser:
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = [torch.cuda.Stream() for _ in range(n)]
-            # branch 0's tokens feed the UNet, so its conditioning is prepared on the main stream
-            prep0 = self._prepared[0] if self._prepared is not None else \
-                self.controlnets[0].prepare_condition(self.camera_param, self.bboxes_list[0], self.prompt_embeds,
-                                                      self.conds[0], self.use_aug_text)
+            # branch 0's TOKENS feed the UNet: only they are prepared on the main stream; the condition
+            # image embedding + SFA of every branch run on the branch's own stream
+            if self._prepared is not None:
+                tok0 = self._prepared[0]
+            else:
+                tok0 = self.controlnets[0].prepare_tokens(self.camera_param, self.bboxes_list[0],
+                                                          self.prompt_embeds, self.use_aug_text)
             results = [None] * n
             for i, cn in enumerate(self.controlnets):                    # fork
                 s = self._side[i]
                 s.wait_stream(main)
                 with torch.cuda.stream(s):
-                    if i == 0:
-                        p_i = prep0
-                    elif self._prepared is not None:
+                    if self._prepared is not None:
                         p_i = self._prepared[i]
+                    elif i == 0:
+                        p_i = cn.prepare_cond(tok0, self.conds[0])
                     else:
                         p_i = cn.prepare_condition(self.camera_param, self.bboxes_list[i], self.prompt_embeds,
                                                    self.conds[i], self.use_aug_text)
                     results[i] = cn.forward_nhwc(x8, m, h, w, self.t_dev, p_i, self.conditioning_scale)
+            prep0 = tok0
             state = self.unet.encode_nhwc(x8, m, h, w, self.t_dev, prep0["ctx2d"], prep0["lc"])
             for s in self._side:                                         # join
                 main.wait_stream(s)
