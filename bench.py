@@ -183,8 +183,8 @@ def _pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed denoising steps (default: one 50-step DDIM sample)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
     ap.add_argument("--hoist-invariant", action="store_true")
