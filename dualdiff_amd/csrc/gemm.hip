@@ -36,6 +36,7 @@ struct GemmParams {
   float* partial;
   int tiles_m, tiles_n;
   uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
+  int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
 };
 
 // --- epilogue on 8 consecutive output channels of one row --------------------------------
@@ -93,7 +94,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // hoisted by the compiler and the tile would pay one memory round trip per 8-column group.
 template <typename T, int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
-                                           int block_n0, int wave_m, int wave_n, int lane) {
+                                           int block_n0, int wave_m, int wave_n, int lane, int row_end) {
   const int q = lane >> 4;
   const int c = lane & 15;
   const int row0 = block_m0 + wave_m * (TM * 16) + c;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int row = row0 + tm * 16;
-      if (row >= p.rows) continue;
+      if (row >= row_end) continue;
 #pragma unroll
       for (int g8 = 0; g8 < NG; ++g8) {
         const int col = col0 + g8 * 8;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int row = row0 + tm * 16;
-        if (row >= p.rows) continue;
+        if (row >= row_end) continue;
 #pragma unroll
         for (int g8 = 0; g8 < NG; ++g8) {
           const int col = col0 + g8 * 8;
@@ -191,7 +192,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int row = row0 + tm * 16;
-      if (row >= p.rows) continue;
+      if (row >= row_end) continue;
 #pragma unroll
       for (int g8 = 0; g8 < NG; ++g8) {
         const int col = col0 + g8 * 8;
@@ -419,7 +420,7 @@ void dd_gemm_kernel(const GemmParams p) {
     buf ^= 1;
   }
 
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane);
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
 }
 
 // =============================================================================================
@@ -666,7 +667,196 @@ void dd_gemm2_kernel(const GemmParams p) {
         for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
   }
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane);
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
+}
+
+// =============================================================================================
+// Kernel family 3: direct 3x3 convolution for SMALL images (14x25 and deeper: H*W <= 384).
+// The implicit-GEMM kernels stage the activation tile once per TAP (9 x per 64 input channels); at
+// the deep levels (336 / 1092 rows x 1280 channels x 29-59 MB of weights) that makes the kernel
+// bytes-in-flight bound.  Here a workgroup owns G whole instances (G*H*W <= BM rows): per 64-channel
+// chunk the RAW pixels of its instances are DMA'd into LDS once, and the 9 taps are 9 different
+// per-lane LDS row gathers (a padding tap points at a row the range check filled with zeros).
+// Staged bytes drop ~5x; the weight matrix is streamed once per row tile through a 3-slot ring.
+// Requirements (host-checked): stride 1, no resize, Cin % 64 == 0.  Split-K is over channel chunks.
+// =============================================================================================
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
+void dd_conv3s_kernel(const GemmParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 16;
+  constexpr int BN = WAVES_N * TN * 16;
+  constexpr int AROWS = BM + 64;               // rows >= BM are never valid pixels -> always zeros
+  constexpr int XA = AROWS / 8 / NW;           // activation DMA pieces per wave per chunk
+  constexpr int WI = BN / 8 / NW;              // weight DMA pieces per wave per (chunk, tap) step
+  // NSW weight ring slots: the weights are cold (HBM, 2-3 us) while a (chunk, tap) step lasts
+  // ~0.3 us, so the ring is as deep as LDS allows
+  static_assert(AROWS % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
+  static_assert(TN % 2 == 0, "TN");
+  static_assert(NSW >= 3 && NSW <= 10 && (NSW - 2) * WI + XA <= 63, "ring depth / vmcnt");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* abuf = reinterpret_cast<T*>(smem);                 // [2][AROWS][64]
+  T* wring = abuf + 2 * AROWS * BK;                     // [NSW][BN][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tile_m = tile / p.tiles_n;
+  const int tile_n = tile % p.tiles_n;
+  const int hw = p.hout * p.wout;
+  const int m_inst = p.rows / hw;
+  const int g0 = tile_m * p.g_per_tile;
+  const int ng = min(p.g_per_tile, m_inst - g0);
+  const int vrows = ng * hw;                            // valid rows of this tile
+  const int row0 = g0 * hw;                             // first global output row
+  const int block_n0 = tile_n * BN;
+
+  const int nchunks = p.cin / BK;
+  const int c_beg = blockIdx.z * p.chunks_per_split;
+  const int nc = min(nchunks, c_beg + p.chunks_per_split) - c_beg;
+  const int nsteps = nc * 9;
+
+  const int lrow = lane >> 3;
+  const int lc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const uint32_t lcb = (uint32_t)lc * 16u;
+
+  // ---- DMA tables -----------------------------------------------------------------------
+  uint32_t av[XA];                                      // activation rows of the tile (raw pixels)
+#pragma unroll
+  for (int j = 0; j < XA; ++j) {
+    const int r = (j * NW + wave) * 8 + lrow;
+    av[j] = r < vrows ? (uint32_t)(row0 + r) * (uint32_t)p.cin * 2u + lcb : DD_OOB;
+  }
+  uint32_t wv[WI];                                      // weight rows, permuted like dd_gemm2_kernel
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int R = (j * NW + wave) * 8 + lrow;
+    const int wvi = R / (TN * 16);
+    const int rho = R % (TN * 16);
+    const int tn = rho >> 4, r = rho & 15;
+    const int col = block_n0 + wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
+    wv[j] = col < p.n ? (uint32_t)col * (uint32_t)p.k * 2u + lcb : DD_OOB;
+  }
+  // ---- per-lane tap tables: LDS row of the pixel each tap reads (BM = the zero row), 2 x 16 bit
+  uint32_t tab[TM][5];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = wave_m * (TM * 16) + tm * 16 + (lane & 15);
+    const bool rv = r < vrows;
+    const int rr = rv ? r : 0;
+    const int g = rr / hw;
+    const int rem = rr - g * hw;
+    const int y = rem / p.wout;
+    const int x = rem - y * p.wout;
+#pragma unroll
+    for (int t2 = 0; t2 < 5; ++t2) {
+      uint32_t packed = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = t2 * 2 + h;
+        uint32_t ra = BM;
+        if (t < 9) {
+          const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+          if (rv && iy >= 0 && iy < p.hout && ix >= 0 && ix < p.wout) ra = (uint32_t)(g * hw + iy * p.wout + ix);
+        }
+        packed |= ra << (16 * h);
+      }
+      tab[tm][t2] = packed;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+
+  auto issue_a = [&](int c) __attribute__((always_inline)) {           // chunk c (local index) -> abuf[c & 1]
+    T* dst = abuf + (c & 1) * AROWS * BK;
+    const uint32_t so = (uint32_t)((c_beg + c) * BK) * 2u;
+#pragma unroll
+    for (int j = 0; j < XA; ++j) bdma16(rs_a, av[j], so, dst + (j * NW + wave) * 8 * BK);
+  };
+  auto issue_w = [&](int c, int t, int slot) __attribute__((always_inline)) {
+    T* dst = wring + slot * BN * BK;
+    const uint32_t so = (uint32_t)(t * p.cin + (c_beg + c) * BK) * 2u;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], so, dst + (j * NW + wave) * 8 * BK);
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fswz = (lane >> 1) & 7;
+  const int fchunk = lane >> 4;
+
+  if (nc > 0) {
+    issue_a(0);
+#pragma unroll
+    for (int s0 = 0; s0 < NSW - 1; ++s0)
+      if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0);
+  }
+  int wslot = 0;                                        // ring slot of step s (scalar)
+  for (int c = 0; c < nc; ++c) {
+    const bool more_c = c + 1 < nc;
+    const T* ab = abuf + (c & 1) * AROWS * BK;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = c * 9 + t;
+      // W(s) (and with it, in issue order, A(c)) must have landed.  Younger loads that may stay in
+      // flight: W(s+1..s+NSW-2), and A(c+1) when it was issued after W(s) (1 <= t <= NSW-2).  The
+      // last NSW-2 steps simply drain.
+      if (s + NSW - 2 < nsteps) {
+        if (t >= 1 && t <= NSW - 2 && more_c) wait_vmcnt<(NSW - 2) * WI + XA>();
+        else wait_vmcnt<(NSW - 2) * WI>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (t == 0 && more_c) issue_a(c + 1);
+      if (s + NSW - 1 < nsteps) {
+        int slot = wslot + NSW - 1;
+        if (slot >= NSW) slot -= NSW;
+        const int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;     // constants after unrolling
+        issue_w(c + ca, ta, slot);
+      }
+      const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
+      if (++wslot == NSW) wslot = 0;
+      V8 wf[2][TN], xf[2][TM];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        uint32_t ra = (tab[j][t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+        asm volatile("" : "+v"(ra));     // keep the 54 gather addresses out of registers: recompute per step
+        const uint32_t c0 = (uint32_t)fchunk ^ ((ra >> 1) & 7u);
+        const T* src = ab + ra * BK;
+        xf[0][j] = dd_as_v8<T>(dd_ld16(src + (c0 << 3)));
+        xf[1][j] = dd_as_v8<T>(dd_ld16(src + ((c0 ^ 4u) << 3)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  // rows past the tile's instances are padding
+  store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows));
 }
 
 // split-K: sum the fp32 partial slabs and run the fused epilogue.
@@ -719,6 +909,11 @@ constexpr TileCfg kTiles[] = {
     // tall tiles for the 4x7 / 7x13 levels (336 / 1092 rows x 1280 x up to 23040): all (or a third of)
     // the rows in one tile so the 29-59 MB weight matrix is streamed once, not once per 128 rows
     {26, 4, 2, 6, 2, 2, "384x64/dma2"},
+    // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
+    // Cin % 64 == 0 / H*W <= rows of the tile only
+    {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
+    {33, 2, 2, 6, 2, -1, "conv3s 192x64/w8"},
+    {34, 2, 2, 6, 2, -1, "conv3s 192x64/w4"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -727,7 +922,7 @@ inline int tile_bn(const TileCfg& t) { return t.wn * t.tn * 16; }
 
 constexpr int kNumCU = 256;
 
-struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; };
+struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -766,6 +961,29 @@ Plan make_plan(const dd_gemm_desc* d) {
       if (oi == 3) ti = geglu ? 2 : 3;
     }
     if (geglu && kTiles[ti].tn % 4 != 0) ti = 2;
+  }
+  if (kTiles[ti].stages < 0) {                       // direct small-image conv
+    const TileCfg& t = kTiles[ti];
+    const int hw = d->hout * d->wout;
+    const bool ok = d->conv && !geglu && d->stride == 1 && d->hv == d->hin && d->wv == d->win &&
+                    d->hout == d->hin && d->wout == d->win && (d->cin % BK) == 0 && hw > 0 &&
+                    hw <= tile_bm(t) && d->rows % hw == 0 && dma_ok(d) && tile_bm(t) < 65535;
+    if (!ok) { pl.unsupported = true; return pl; }
+    const int m_inst = d->rows / hw;
+    int g = tile_bm(t) / hw;
+    if (g > m_inst) g = m_inst;
+    const int nchunks = d->cin / BK;
+    int split = d->split_k > 0 ? d->split_k : 1;
+    if (split > nchunks) split = nchunks;
+    const int cps = ceil_div(nchunks, split);
+    pl.tile_idx = ti;
+    pl.g_per_tile = g;
+    pl.tiles_m = ceil_div(m_inst, g);
+    pl.tiles_n = ceil_div(d->n, tile_bn(t));
+    pl.chunks_per_split = cps;
+    pl.split = ceil_div(nchunks, cps);
+    pl.k_per_split = cps * BK;
+    return pl;
   }
   if (kTiles[ti].stages && !dma_ok(d)) {             // same tile shape, register-staged family
     int alt = geglu ? 0 : 3;                          // no twin: 128x128 (GEGLU-capable) / 64x64
@@ -832,9 +1050,29 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
+template <typename T, int WM, int WN, int TM, int TN, int NSW>
+int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr size_t smem = (size_t)(2 * (BM + 64) + NSW * BN) * BK * sizeof(T);
+  static_assert(smem <= 160 * 1024, "LDS");
+  auto kern = dd_conv3s_kernel<T, WM, WN, TM, TN, NSW>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
+  return dd_check_launch();
+}
+
 template <typename T, bool CONV, bool GEGLU>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
   switch (kTiles[pl.tile_idx].id) {
+    case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
+    case 33: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 8>(p, pl, s); break;
+    case 34: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 4>(p, pl, s); break;
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
     case 14: return launch_cfg2<T, 2, 2, 2, 4, 3, CONV, GEGLU>(p, pl, s);
@@ -921,14 +1159,20 @@ extern "C" int dd_gemm_tile_id(int index) { return (index >= 0 && index < kNumTi
 extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
   if (validate(d) != DD_OK) return 0;
   const Plan pl = make_plan(d);
-  if (pl.split <= 1) return 0;
+  if (pl.unsupported || pl.split <= 1) return 0;
   return (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
 }
 
 extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   if (validate(d) != DD_OK) return "invalid";
   const Plan pl = make_plan(d);
+  if (pl.unsupported) return "unsupported";
   const TileCfg& t = kTiles[pl.tile_idx];
+  if (t.stages < 0) {
+    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : 4), pl.split, pl.tiles_m, pl.tiles_n, t.name);
+    return g_kname;
+  }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
   char stage[16] = "";
   if (t.stages) snprintf(stage, sizeof(stage), " %d,", t.stages);
@@ -943,7 +1187,9 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   const int vc = validate(d);
   if (vc != DD_OK) return vc;
   const Plan pl = make_plan(d);
+  if (pl.unsupported) return DD_ERR_UNSUPPORTED;
   GemmParams p{};
+  p.g_per_tile = pl.g_per_tile; p.chunks_per_split = pl.chunks_per_split;
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;

@@ -157,6 +157,48 @@ def test_conv3x3_dma_tiles(ops, tile, case):
         check(y, ref, dtype, "conv dma tile%d split%d %s" % (tile, split, case))
 
 
+CONV3S_TILES = [31, 33, 34]
+# (m, h, w, cin, cout): 4x7 / 7x13 / 14x25 levels, ragged instance counts (partial last tile), one
+# instance per tile, Cout not a multiple of the tile
+CONV3S_CASES = [(12, 4, 7, 1280, 1280), (5, 4, 7, 128, 192), (12, 7, 13, 640, 1280), (7, 7, 13, 192, 64),
+                (3, 14, 25, 640, 640), (1, 4, 7, 64, 72), (13, 2, 3, 64, 64)]
+
+
+@pytest.mark.parametrize("tile", CONV3S_TILES)
+@pytest.mark.parametrize("case", CONV3S_CASES, ids=lambda c: str(c))
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_small_image_direct(ops, tile, case, dtype):
+    """Direct small-image conv family (dd_conv3s_kernel): whole instances per workgroup, taps as LDS
+    row gathers; with the ResnetBlock2D epilogue and split-K over channel chunks."""
+    m, h, w_, cin, cout = case
+    if h * w_ > (384 if tile == 31 else 192):
+        pytest.skip("image larger than the tile")
+    x = rnd((m * h * w_, cin), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    temb = rnd((m, cout), dtype, 4)
+    res = rnd((m * h * w_, cout), dtype, 5)
+    ref = L.conv3x3_ref(x, w, b, m, h, w_) + temb.float().cpu().repeat_interleave(h * w_, 0) + res.float().cpu()
+    for split in (1, 2, 5):
+        if split > cin // 64:
+            continue
+        y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split)
+        check(y, ref, dtype, "conv3s tile%d split%d %s" % (tile, split, case))
+
+
+def test_conv3x3_small_image_direct_rejects(ops):
+    """Shapes outside the family's contract are refused (the autotuner skips them), never mis-run."""
+    dtype = torch.bfloat16
+    x = rnd((2 * 28 * 50, 320), dtype, 1)
+    w = rnd((320, 320, 3, 3), dtype, 2, 0.02)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3(x, L.pack_conv_weight(w), None, 2, 28, 50, tile=31)          # 1400 pixels > 384
+    x = rnd((2 * 14 * 25, 640), dtype, 1)
+    w = rnd((640, 640, 3, 3), dtype, 2, 0.02)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3(x, L.pack_conv_weight(w), None, 2, 14, 25, stride=2, tile=31)  # stride 2
+
+
 @pytest.mark.parametrize("tile", [11, 12, 14, 16, 20])
 def test_gemm_geglu_dma_tiles(ops, tile):
     dtype = torch.bfloat16
