@@ -30,7 +30,8 @@ def _hipcc():
 
 
 def lib_path():
-    return os.path.join(LIBDIR, LIBNAME)
+    # DD_HIP_LIB: load an alternative build of the same C-ABI (A/B experiments on kernel variants)
+    return os.environ.get("DD_HIP_LIB") or os.path.join(LIBDIR, LIBNAME)
 
 
 def _deps():

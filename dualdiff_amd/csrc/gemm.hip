@@ -642,6 +642,7 @@ void dd_gemm2_kernel(const GemmParams p) {
       else wait_vmcnt<(NSTAGE > 7 ? 6 : 0) * LPS>();
     }
     __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
+    // (issuing the DMAs after the fragment reads, or between the two MFMA halves, measured the same)
     if (kt + NSTAGE - 1 < nk) issue_next((kt + NSTAGE - 1) % NSTAGE);
     const int slot = kt % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
@@ -660,11 +661,12 @@ void dd_gemm2_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+    }
     __builtin_amdgcn_s_setprio(0);
   }
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
