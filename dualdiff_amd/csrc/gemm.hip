@@ -37,6 +37,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
   int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
+  const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
 };
 
 // --- epilogue on 8 consecutive output channels of one row --------------------------------
@@ -90,11 +91,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // acc[tn][tm][reg]: output row = tile row tm*16 + (lane & 15),
 //                   output col = q*(4*TN) + tn*4 + reg  (q = lane >> 4)   [non-GEGLU]
 // Every global read of the epilogue (bias, time-embedding vector, residual, accumulate target) is
-// issued BEFORE the first store: `out` may alias `res`, so a load placed after a store could not be
-// hoisted by the compiler and the tile would pay one memory round trip per 8-column group.
+// issued before the stores of its row batch: `out` may alias `res`, so a load placed after a store could
+// not be hoisted by the compiler and the tile would pay one memory round trip per 8-column group.
 template <typename T, int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
-                                           int block_n0, int wave_m, int wave_n, int lane, int row_end) {
+                                           int block_n0, int wave_m, int wave_n, int lane, int row_end,
+                                           const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
   const int q = lane >> 4;
   const int c = lane & 15;
   const int row0 = block_m0 + wave_m * (TM * 16) + c;
@@ -103,6 +105,20 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
     constexpr int NG = TH / 2;
     const int col0 = block_n0 + wave_n * (TH * 16) + q * (4 * TH);
     u32x4 bh[NG], bg[NG];
+    f32x4 lsh[NG][2], lsg[NG][2], lbh[NG][2], lbg[NG][2];     // LayerNorm fold: column sums / folded bias
+    if (ln_mean) {
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
+        const int col = min(col0 + g8 * 8, p.n - 8);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          lsh[g8][h2] = *reinterpret_cast<const f32x4*>(p.ln_colsum + col + 4 * h2);
+          lsg[g8][h2] = *reinterpret_cast<const f32x4*>(p.ln_colsum + p.n + col + 4 * h2);
+          lbh[g8][h2] = *reinterpret_cast<const f32x4*>(p.ln_bias + col + 4 * h2);
+          lbg[g8][h2] = *reinterpret_cast<const f32x4*>(p.ln_bias + p.n + col + 4 * h2);
+        }
+      }
+    }
     if (p.bias) {
 #pragma unroll
       for (int g8 = 0; g8 < NG; ++g8) {
@@ -124,6 +140,15 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         for (int e = 0; e < 8; ++e) {
           h[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
           g[e] = acc[TH + g8 * 2 + (e >> 2)][tm][e & 3];
+        }
+        if (ln_mean) {
+          const int lr = wave_m * (TM * 16) + tm * 16 + c;
+          const float mu = ln_mean[lr], rs = ln_rstd[lr];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            h[e] = rs * (h[e] - mu * lsh[g8][e >> 2][e & 3]) + lbh[g8][e >> 2][e & 3];
+            g[e] = rs * (g[e] - mu * lsg[g8][e >> 2][e & 3]) + lbg[g8][e >> 2][e & 3];
+          }
         }
         if (p.bias) {
           float b[8];
@@ -159,8 +184,11 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
       }
       return;
     }
-    // ---- phase 1: all loads (clamped addresses: every lane loads, nothing is predicated) ----
-    u32x4 rb[NG], rv[TM][NG], rr[TM][NG], ra[TM][NG];
+    // Rows are handled in (at most) two batches: per batch, phase 1 issues ALL its loads (clamped
+    // addresses, nothing predicated), phase 2 does the arithmetic and the stores.  One batch would
+    // keep TM*TN/2*3 16-B vectors live next to the accumulators (128x128 tile: > 256 VGPRs).
+    constexpr int TMB = TM >= 4 ? TM / 2 : TM;
+    u32x4 rb[NG];
     int colc[NG];
 #pragma unroll
     for (int g8 = 0; g8 < NG; ++g8) colc[g8] = min(col0 + g8 * 8, p.n - 8);
@@ -168,65 +196,86 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
       for (int g8 = 0; g8 < NG; ++g8) rb[g8] = dd_ld16(reinterpret_cast<const T*>(p.bias) + colc[g8]);
     }
+    f32x4 lcs[NG][2], lcb[NG][2];                        // LayerNorm fold: column sums / folded bias
+    if (ln_mean) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int rowc = min(row0 + tm * 16, p.rows - 1);
-      if (p.rowvec) {
-        const int inst = rowc / p.rows_per_inst;
+      for (int g8 = 0; g8 < NG; ++g8)
 #pragma unroll
-        for (int g8 = 0; g8 < NG; ++g8)
-          rv[tm][g8] = dd_ld16(reinterpret_cast<const T*>(p.rowvec) + (int64_t)inst * p.ld_rowvec + colc[g8]);
-      }
-      if (p.res) {
-#pragma unroll
-        for (int g8 = 0; g8 < NG; ++g8)
-          rr[tm][g8] = dd_ld16(reinterpret_cast<const T*>(p.res) + (int64_t)rowc * p.ldres + colc[g8]);
-      }
-      if (p.accumulate) {
-#pragma unroll
-        for (int g8 = 0; g8 < NG; ++g8)
-          ra[tm][g8] = dd_ld16(reinterpret_cast<const T*>(p.out) + (int64_t)rowc * p.ldc + colc[g8]);
-      }
+        for (int h2 = 0; h2 < 2; ++h2) {
+          lcs[g8][h2] = *reinterpret_cast<const f32x4*>(p.ln_colsum + colc[g8] + 4 * h2);
+          lcb[g8][h2] = *reinterpret_cast<const f32x4*>(p.ln_bias + colc[g8] + 4 * h2);
+        }
     }
-    // ---- phase 2: arithmetic in the reference's order (bias, time vector, alpha, residual, act, accumulate) + stores ----
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int row = row0 + tm * 16;
-      if (row >= row_end) continue;
+    for (int tb = 0; tb < TM; tb += TMB) {
+      u32x4 rv[TMB][NG], rr[TMB][NG], ra[TMB][NG];
 #pragma unroll
-      for (int g8 = 0; g8 < NG; ++g8) {
-        const int col = col0 + g8 * 8;
-        if (col >= p.n) continue;
-        float v[8], b[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
-        if (p.bias) {
-          dd_unpack8<T>(rb[g8], b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
-        }
+      for (int t2 = 0; t2 < TMB; ++t2) {
+        const int rowc = min(row0 + (tb + t2) * 16, p.rows - 1);
         if (p.rowvec) {
-          dd_unpack8<T>(rv[tm][g8], b);
+          const int inst = rowc / p.rows_per_inst;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
+          for (int g8 = 0; g8 < NG; ++g8)
+            rv[t2][g8] = dd_ld16(reinterpret_cast<const T*>(p.rowvec) + (int64_t)inst * p.ld_rowvec + colc[g8]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
         if (p.res) {
-          dd_unpack8<T>(rr[tm][g8], b);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
-        }
-        if (p.act == DD_EPI_SILU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = dd_silu_f(v[e]);
+          for (int g8 = 0; g8 < NG; ++g8)
+            rr[t2][g8] = dd_ld16(reinterpret_cast<const T*>(p.res) + (int64_t)rowc * p.ldres + colc[g8]);
         }
         if (p.accumulate) {
-          dd_unpack8<T>(ra[tm][g8], b);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
+          for (int g8 = 0; g8 < NG; ++g8)
+            ra[t2][g8] = dd_ld16(reinterpret_cast<const T*>(p.out) + (int64_t)rowc * p.ldc + colc[g8]);
         }
-        dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
+      }
+      // arithmetic in the reference's order (bias, time vector, alpha, residual, act, accumulate) + stores
+#pragma unroll
+      for (int t2 = 0; t2 < TMB; ++t2) {
+        const int tm = tb + t2;
+        const int row = row0 + tm * 16;
+        if (row >= row_end) continue;
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8) {
+          const int col = col0 + g8 * 8;
+          if (col >= p.n) continue;
+          float v[8], b[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+          if (ln_mean) {
+            const int lr = wave_m * (TM * 16) + tm * 16 + c;
+            const float mu = ln_mean[lr], rs = ln_rstd[lr];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rs * (v[e] - mu * lcs[g8][e >> 2][e & 3]) + lcb[g8][e >> 2][e & 3];
+          }
+          if (p.bias) {
+            dd_unpack8<T>(rb[g8], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+          if (p.rowvec) {
+            dd_unpack8<T>(rv[t2][g8], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          if (p.res) {
+            dd_unpack8<T>(rr[t2][g8], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+          if (p.act == DD_EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = dd_silu_f(v[e]);
+          }
+          if (p.accumulate) {
+            dd_unpack8<T>(ra[t2][g8], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+          dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
+        }
       }
     }
   }
@@ -627,6 +676,39 @@ void dd_gemm2_kernel(const GemmParams p) {
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
     if (s0 < nk) issue_next(s0);
 
+  // LayerNorm fold: row statistics of the block's A rows (K = 40 * lpr columns: lpr lanes share a
+  // row, five 16-B vectors per lane), computed while the first stages are in flight.
+  __shared__ float s_ln_mean[BM], s_ln_rstd[BM];
+  if (!CONV && p.ln_colsum) {
+    const int lpr = p.k / 40;                           // 8 / 16 / 32 (host-checked)
+    const int rpw = 64 / lpr;
+    const int sub = lane & (lpr - 1);
+    const float inv_k = 1.0f / (float)p.k;
+    for (int r0 = wave * rpw; r0 < BM; r0 += NW * rpw) {
+      const int r = r0 + lane / lpr;
+      const int64_t grow = min(block_m0 + r, p.rows - 1);
+      float sum = 0.f, sq = 0.f;
+      u32x4 raw[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        raw[i] = dd_ld16(reinterpret_cast<const T*>(p.a) + grow * p.lda + (sub + i * lpr) * 8);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        float f[8];
+        dd_unpack8<T>(raw[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sum += f[e]; sq += f[e] * f[e]; }
+      }
+      for (int o = lpr >> 1; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+      if (sub == 0) {
+        const float mean = sum * inv_k;
+        s_ln_mean[r] = mean;
+        s_ln_rstd[r] = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
+      }
+    }
+    __syncthreads();
+  }
+
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
     if (NSTAGE == 2) {
@@ -669,7 +751,9 @@ void dd_gemm2_kernel(const GemmParams p) {
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
+  const bool ln = !CONV && p.ln_colsum;
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
+                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr);
 }
 
 // =============================================================================================
@@ -964,6 +1048,13 @@ Plan make_plan(const dd_gemm_desc* d) {
     }
     if (geglu && kTiles[ti].tn % 4 != 0) ti = 2;
   }
+  if (d->ln_colsum) {                                // LayerNorm fold lives in the LDS-DMA family only
+    if (d->tile <= 0) {                              // heuristic picked a register-staged tile: take its twin
+      const int twin[4] = {11, 17, 14, 18};
+      for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == twin[ti < 4 ? ti : 3]) { ti = i; break; }
+    }
+    if (kTiles[ti].stages <= 0 || !dma_ok(d)) { pl.unsupported = true; return pl; }
+  }
   if (kTiles[ti].stages < 0) {                       // direct small-image conv
     const TileCfg& t = kTiles[ti];
     const int hw = d->hout * d->wout;
@@ -1011,7 +1102,7 @@ Plan make_plan(const dd_gemm_desc* d) {
       if (split < 1) split = 1;
     }
   }
-  if (geglu) split = 1;
+  if (geglu || d->ln_colsum) split = 1;
   if (split > nkt) split = nkt;
   int kts = ceil_div(nkt, split);
   split = ceil_div(nkt, kts);
@@ -1125,6 +1216,11 @@ int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hip
 
 int validate(const dd_gemm_desc* d) {
   if (!d || !d->a || !d->w || !d->out) return DD_ERR_BAD_ARG;
+  if (d->ln_colsum) {                                  // LayerNorm fold
+    if (!d->ln_bias || d->conv || d->a2 || d->bias) return DD_ERR_BAD_ARG;
+    if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
+    if (!dd_aligned16(d->ln_colsum) || !dd_aligned16(d->ln_bias) || (d->lda & 7)) return DD_ERR_BAD_ARG;
+  }
   if (d->rows <= 0 || d->n <= 0 || d->k <= 0) return DD_ERR_BAD_ARG;
   if ((d->k & 7) || (d->n & 7) || (d->ldc & 7)) return DD_ERR_BAD_ARG;
   if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;
@@ -1192,6 +1288,9 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   if (pl.unsupported) return DD_ERR_UNSUPPORTED;
   GemmParams p{};
   p.g_per_tile = pl.g_per_tile; p.chunks_per_split = pl.chunks_per_split;
+  p.ln_colsum = reinterpret_cast<const float*>(d->ln_colsum);
+  p.ln_bias = reinterpret_cast<const float*>(d->ln_bias);
+  p.ln_eps = d->ln_eps;
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;

@@ -76,13 +76,12 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         return self._maps[key]
 
     def run(self, h, batch, l, ctx2d, lc):
-        h = self._attn(self.attn1, self.norm1.run(h), h, batch, l)
-        h = self._attn(self.attn2, self.norm2.run(h), h, batch, l, ctx2d, lc)
+        h = self._attn(self.attn1, self.norm1, h, batch, l)
+        h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
         # ---- neighbour-view attention ------------------------------------------------------
         a = self.attn4
         c = a.inner_dim
-        x = self.norm4.run(h)
-        qkv = a.project_qkv(x)
+        qkv = a.project_qkv(h, self.norm4)
         maps = self.neighbour_maps(batch, h.device)
         o = None
         for j, mp in enumerate(maps):
@@ -98,4 +97,4 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
             h = self.connector.run(y, res=h)
         # ---- feed-forward ------------------------------------------------------------------
-        return self.ff.run(self.norm3.run(h), res=h)
+        return self.ff.run(h, res=h, norm=self.norm3)

@@ -85,6 +85,13 @@ class Linear(_Cached):
             x2d = torch.nn.functional.pad(x2d, (0, w.shape[1] - x2d.shape[1]))
         return O.gemm(x2d, w, self.bias, **kw)
 
+    def run_ln(self, x2d, norm, **kw):
+        """LayerNorm(norm) + this Linear as one GEMM on the UN-normalised x2d (fold_layernorm)."""
+        if not ln_fold_ok(norm, self.in_features, self.out_features):
+            return self.run(norm.run(x2d), **kw)
+        w, ln = fold_layernorm(self.__dict__, "_pk_ln", norm, [self.weight], [self.bias])
+        return O.gemm(x2d, w, None, ln=ln, **kw)
+
     def forward(self, x):
         """Tensor-in / tensor-out form used by foreign attention processors:
         (..., K) tokens, or (m, K, h, w) NCHW for the 1x1-conv flavour."""
@@ -159,6 +166,42 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         return self.run(x.reshape(-1, x.shape[-1])).reshape(x.shape)
+
+
+# LayerNorm fold policy (dd_gemm's ln_colsum path).  Every column tile of the consumer GEMM recomputes
+# the statistics of its rows, and that costs more than the LayerNorm launch it removes: measured on
+# config 2, folding all four norms (QKV is 3C wide, the GEGLU projection 8C) LOSES 5 % (72.8 -> 68.9
+# steps/s), folding only the C-wide to_q of attn2 is neutral (73.1 vs 73.1-75).  Off by default;
+# DD_LN_FOLD=all / q turn it on.
+LN_FOLD = __import__("os").environ.get("DD_LN_FOLD", "0")
+
+
+def ln_fold_ok(norm, k, n=None):
+    """The kernel-side fold covers the transformer widths of this network."""
+    if LN_FOLD == "0" or not isinstance(norm, LayerNorm) or k not in (320, 640, 1280):
+        return False
+    return LN_FOLD == "all" or (n is not None and n <= k)
+
+
+def fold_layernorm(cache, key, norm, weights, biases):
+    """LayerNorm(x) @ W^T + b  ==  rstd * (x @ W'^T - mean * colsum) + b'   with
+    W' = W * gamma, colsum[n] = sum_k W'[n,k] (of the ROUNDED W', the matrix the kernel multiplies by),
+    b' = W beta + b.  `weights` / `biases`: lists concatenated along N (fused projections).
+    Cached in `cache[key]` until any involved parameter changes.  Returns (W', (colsum, b', eps))."""
+    params = [norm.weight, norm.bias] + list(weights) + [b for b in biases if b is not None]
+    ver = tuple((t._version, t.data_ptr()) for t in params)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        w = torch.cat([t.detach().reshape(t.shape[0], -1) for t in weights], dim=0).float()
+        b = torch.cat([(bb.detach().float() if bb is not None else torch.zeros(t.shape[0], device=t.device))
+                       for t, bb in zip(weights, biases)])
+        wp = (w * norm.weight.detach().float()[None, :]).to(weights[0].dtype).contiguous()
+        colsum = wp.float().sum(dim=1).contiguous()
+        lnb = (w @ norm.bias.detach().float() + b).contiguous()
+    cache[key] = (ver, wp, (colsum, lnb, norm.eps))
+    return wp, (colsum, lnb, norm.eps)
 
 
 class _Dropout(nn.Module):
@@ -303,24 +346,31 @@ class Attention(_Cached):
     def _drop_cache(self):
         super()._drop_cache()
 
-    def project_qkv(self, x2d):
-        """One GEMM for Q, K, V of a self-attention style layer -> (rows, 3*inner)."""
+    def project_qkv(self, x2d, norm=None):
+        """One GEMM for Q, K, V of a self-attention style layer -> (rows, 3*inner).  With `norm`,
+        x2d is the un-normalised input and the LayerNorm is folded into the GEMM."""
+        if norm is not None:
+            if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim):
+                return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")))
+            mods = (self.to_q, self.to_k, self.to_v)
+            w, ln = fold_layernorm(self.__dict__, "_pk_ln_qkv", norm, [m.weight for m in mods], [m.bias for m in mods])
+            return O.gemm(x2d, w, None, ln=ln)
         return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")))
 
     def project_kv(self, ctx2d):
         """K and V of the context in one GEMM -> (rows_ctx, 2*inner)."""
         return O.gemm(ctx2d, self._fused(("to_k", "to_v")))
 
-    def run_self(self, x2d, batch, lq, res=None):
+    def run_self(self, x2d, batch, lq, res=None, norm=None):
         c = self.inner_dim
-        qkv = self.project_qkv(x2d)
+        qkv = self.project_qkv(x2d, norm)
         o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, lq, lq, self.heads,
                         self.dim_head, self.scale)
         return self.to_out[0].run(o, res=res)
 
-    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None):
+    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None):
         c = self.inner_dim
-        q = self.to_q.run(x2d)
+        q = self.to_q.run(x2d) if norm is None else self.to_q.run_ln(x2d, norm)
         pre = self.__dict__.pop("_kv_prefetched", None)
         if kv is None and pre is not None and pre[0] is ctx2d:
             kv, side = pre[1], pre[2]                # projected ahead of time on a side stream
@@ -373,8 +423,11 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), _Dropout(), Linear(dim * mult, dim)])
 
-    def run(self, x2d, res=None):
-        g = self.net[0].proj.run(x2d, epilogue=O.DD_EPI_GEGLU)
+    def run(self, x2d, res=None, norm=None):
+        if norm is None:
+            g = self.net[0].proj.run(x2d, epilogue=O.DD_EPI_GEGLU)
+        else:
+            g = self.net[0].proj.run_ln(x2d, norm, epilogue=O.DD_EPI_GEGLU)
         return self.net[2].run(g, res=res)
 
 
@@ -391,21 +444,22 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def _attn(self, attn, x_norm, h, batch, l, ctx=None, lc=0):
-        """Runs `attn` (+ residual h).  Foreign processors get (B, L, C) tensors through the
-        diffusers protocol; the built-in one fuses the residual into the out-projection."""
+    def _attn(self, attn, norm, h, batch, l, ctx=None, lc=0):
+        """LayerNorm `norm` + `attn` (+ residual h).  The built-in processor folds the LayerNorm
+        into the Q(KV) projection and the residual into the out-projection; foreign processors get
+        the normalised (B, L, C) tensor through the diffusers protocol."""
         if isinstance(attn.processor, HIPAttnProcessor):
             if ctx is None:
-                return attn.run_self(x_norm, batch, l, res=h)
-            return attn.run_cross(x_norm, batch, l, ctx, lc, res=h)
+                return attn.run_self(h, batch, l, res=h, norm=norm)
+            return attn.run_cross(h, batch, l, ctx, lc, res=h, norm=norm)
         e = None if ctx is None else ctx.reshape(batch, lc, -1)
-        out = attn(x_norm.reshape(batch, l, -1), encoder_hidden_states=e)
+        out = attn(norm.run(h).reshape(batch, l, -1), encoder_hidden_states=e)
         return O.add(out.reshape(batch * l, -1).contiguous(), h)
 
     def run(self, h, batch, l, ctx2d, lc):
-        h = self._attn(self.attn1, self.norm1.run(h), h, batch, l)
-        h = self._attn(self.attn2, self.norm2.run(h), h, batch, l, ctx2d, lc)
-        return self.ff.run(self.norm3.run(h), res=h)
+        h = self._attn(self.attn1, self.norm1, h, batch, l)
+        h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
+        return self.ff.run(h, res=h, norm=self.norm3)
 
 
 class Transformer2DModel(nn.Module):

@@ -228,8 +228,11 @@ def _rows2d(t):
 
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
-         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0):
-    """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused)."""
+         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None):
+    """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
+
+    ln = (colsum_f32, bias_f32, eps): LayerNorm fold — `a` is the UN-normalised input, `w` the
+    gamma-scaled weight; the kernel computes the row statistics itself (include/dualdiff_hip.h)."""
     lib = _native.load()
     _need_gpu(a, w, bias, a2, res, rowvec, out)
     a = _rows2d(a)
@@ -261,8 +264,16 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     d.alpha = alpha; d.accumulate = int(accumulate); d.epilogue = epilogue
     d.conv = 0
     d.dtype = _dt(a); d.tile = tile; d.split_k = split_k
+    if ln is not None:
+        if bias is not None or a2 is not None:
+            raise ValueError("gemm(ln=...) folds the bias and takes a single source")
+        colsum, lnb, eps = ln
+        _need_gpu(colsum, lnb)
+        if colsum.dtype != torch.float32 or lnb.dtype != torch.float32 or colsum.numel() != n_w or lnb.numel() != n_w:
+            raise ValueError("ln fold vectors must be fp32 with %d entries" % n_w)
+        d.ln_colsum, d.ln_bias, d.ln_eps = colsum.data_ptr(), lnb.data_ptr(), float(eps)
     if tile == 0 and split_k == 0:
-        d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None),
+        d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None),
                                       (rows, n), a.dtype, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:

@@ -106,6 +106,17 @@ typedef struct dd_gemm_desc {
   int32_t split_k;     /* 0 = auto, 1 = off, >1 = number of K slices */
   void* ws;            /* fp32 workspace for split-K partials */
   int64_t ws_bytes;
+  /* LayerNorm fold (dense mode, K in {320, 640, 1280}, no a2, no split-K): `a` holds the
+   * UN-normalised rows x; the kernel computes each row's mean / rstd over its K columns in its
+   * prologue and evaluates  LN(x) W^T + b  as
+   *     rstd_r * (x W'^T - mean_r * ln_colsum) + ln_bias,
+   * with W' = W * gamma (passed as `w`), ln_colsum[n] = sum_k W'[n,k], ln_bias[n] = W beta + b
+   * (both fp32, n_w entries).  Replaces LayerNorm + Linear of norm1->to_q/k/v, norm2->to_q,
+   * norm4->attn4 q/k/v, norm3->GEGLU proj (blocks.py:150-236).  `bias` must be NULL.  */
+  const void* ln_colsum;   /* NULL = no fold */
+  const void* ln_bias;
+  float ln_eps;
+  int32_t reserved0;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);

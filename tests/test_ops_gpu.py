@@ -199,6 +199,61 @@ def test_conv3x3_small_image_direct_rejects(ops):
         ops.conv3x3(x, L.pack_conv_weight(w), None, 2, 14, 25, stride=2, tile=31)  # stride 2
 
 
+def _ln_fold(w, b, gamma, beta, dtype):
+    """W' = W * gamma (rounded to the storage dtype), colsum of the rounded W', b' = W beta + b."""
+    wf = w.float()
+    wp = (wf * gamma.float()[None, :]).to(dtype).contiguous()
+    lnb = wf @ beta.float() + (b.float() if b is not None else 0)
+    return wp, wp.float().sum(1).contiguous(), lnb.contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c,n,tile", [(700, 320, 960, 0), (16800, 320, 320, 17), (350, 640, 1920, 11),
+                                          (91, 1280, 3840, 0), (1092, 1280, 1280, 15), (37, 640, 640, 18),
+                                          (4200, 640, 640, 19), (336, 1280, 1280, 21), (129, 320, 64, 26)])
+def test_gemm_layernorm_fold(ops, dtype, rows, c, n, tile):
+    """LayerNorm folded into the consumer GEMM (row statistics in the kernel prologue) against
+    LayerNorm -> Linear of the reference; input with a non-zero row mean and per-row scale."""
+    x = (rnd((rows, c), dtype, 1).float() * (0.5 + rnd((rows, 1), torch.float32, 7).abs()) + 0.7).to(dtype)
+    w = rnd((n, c), dtype, 2, c ** -0.5)
+    b = rnd((n,), dtype, 3)
+    gamma = (1.0 + 0.2 * rnd((c,), torch.float32, 4)).to(dtype)
+    beta = (0.1 * rnd((c,), torch.float32, 5)).to(dtype)
+    res = rnd((rows, n), dtype, 6)
+    wp, colsum, lnb = _ln_fold(w, b, gamma, beta, dtype)
+    y = ops.gemm(x, wp, None, res=res, ln=(colsum, lnb, 1e-5), tile=tile)
+    ref = L.linear_ref(L.layernorm_ref(x, gamma, beta, 1e-5), w, b, res=res)
+    check(y, ref, dtype, "gemm + LN fold %dx%dx%d tile%d" % (rows, n, c, tile), 2.0)
+
+
+@pytest.mark.parametrize("tile", [11, 14, 20])
+def test_gemm_layernorm_fold_geglu(ops, tile):
+    dtype = torch.bfloat16
+    rows, c = 700, 640
+    x = (rnd((rows, c), dtype, 1).float() * 1.5 - 0.4).to(dtype)
+    w = rnd((8 * c, c), dtype, 2, c ** -0.5)
+    b = rnd((8 * c,), dtype, 3)
+    gamma = (1.0 + 0.2 * rnd((c,), torch.float32, 4)).to(dtype)
+    beta = (0.1 * rnd((c,), torch.float32, 5)).to(dtype)
+    wp, colsum, lnb = _ln_fold(w, b, gamma, beta, dtype)
+    y = ops.gemm(x, wp, None, ln=(colsum, lnb, 1e-5), epilogue=ops.DD_EPI_GEGLU, tile=tile)
+    ref = L.linear_ref(L.layernorm_ref(x, gamma, beta, 1e-5), w, b, geglu=True)
+    check(y, ref, dtype, "geglu + LN fold tile%d" % tile, 3.0)
+
+
+def test_gemm_layernorm_fold_rejects(ops):
+    dtype = torch.bfloat16
+    x = rnd((64, 512), dtype, 1)
+    w = rnd((64, 512), dtype, 2)
+    z = torch.zeros(64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, None, ln=(z, z, 1e-5))                 # K outside {320, 640, 1280}
+    x = rnd((64, 320), dtype, 1)
+    w = rnd((64, 320), dtype, 2)
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, None, ln=(z, z, 1e-5), tile=1)         # register-staged family has no fold
+
+
 @pytest.mark.parametrize("tile", [11, 12, 14, 16, 20])
 def test_gemm_geglu_dma_tiles(ops, tile):
     dtype = torch.bfloat16
