@@ -167,10 +167,6 @@ void dd_attn_kernel(const AttnParams p) {
       // ---- S^T = K Q^T for 32 keys ------------------------------------------------------
       f32x4 sacc[2][QT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < QT; ++j) sacc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         V8 kf[2];
 #pragma unroll
@@ -179,7 +175,8 @@ void dd_attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int j = 0; j < QT; ++j) sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], sacc[t][j]);
+          for (int j = 0; j < QT; ++j)   // first K-step accumulates onto a literal zero: no v_mov to clear sacc
+            sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[t][j]);
       }
       // ---- online softmax; lane holds keys key0 + t*16 + g*4 + r for query column c -------
       const bool tail = key0 + 32 > p.lk;             // uniform; only the last chunk is masked
@@ -198,17 +195,18 @@ void dd_attn_kernel(const AttnParams p) {
             for (int r = 0; r < 4; ++r)
               if (key0 + t * 16 + g * 4 + r >= p.lk) s[t * 4 + r] = -INFINITY;
         }
-        // max on the raw scores (scale > 0), one multiply for the row, scale folded into the fma
-        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
-                         fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // Deferred rescale: the running max (and the O / l accumulators) are only moved when some
-        // row's max grew by more than 2^RESCALE_THR; until then probabilities are taken against the
-        // old max and may reach 2^RESCALE_THR — exact in floating point up to the usual rounding.
-        const float m_cand = mx * p.scale_log2;
-        if (__any(m_cand - m_run[j] > RESCALE_THR)) {   // wave-uniform, rare after the first tiles
-          const float m_new = fmaxf(m_run[j], m_cand);
+        // Lane-local max of the lane's 8 scores (scale > 0).  Deferred rescale: the running max (and
+        // the O / l accumulators) only move when SOME lane sees a score more than 2^RESCALE_THR above
+        // it; until then probabilities are taken against the old max (they may reach 2^RESCALE_THR —
+        // exact in floating point up to the usual rounding).  The cross-lane max over the four key
+        // groups (two ds_bpermute round trips on the critical path) is therefore only taken inside
+        // the rare branch; the common case needs a compare and a wave-wide `any`.
+        const float mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
+                                 fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {   // wave-uniform, rare after the first tiles
+          float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
           const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
           m_run[j] = m_new;
           if (!ONES) l_run[j] *= alpha;
