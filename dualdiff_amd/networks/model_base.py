@@ -79,9 +79,8 @@ class ModelBase(nn.Module):
             raise ValueError(
                 f"A dict of processors was passed, but the number of processors {len(processor)} does not "
                 f"match the number of attention layers: {count}.")
-        for name, m in self.named_modules():
-            if hasattr(m, "set_processor"):
-                m.set_processor(processor.pop(name + ".processor") if isinstance(processor, dict) else processor)
+        for name, m in [(n, mm) for n, mm in self.named_modules() if hasattr(mm, "set_processor")]:
+            m.set_processor(processor.pop(name + ".processor") if isinstance(processor, dict) else processor)
 
     def set_default_attn_processor(self):
         self.set_attn_processor(HIPAttnProcessor())

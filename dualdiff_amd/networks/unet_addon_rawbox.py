@@ -262,23 +262,36 @@ class BEVControlNetModel(ModelBase):
         dt = self.dtype
         b, n_cam = camera_param.shape[:2]
         ctx = self.add_cam_states(encoder_hidden_states, self._embed_camera(camera_param))    # b, n, L+1, 768
-        box = None
+        box = cls = None
         if bboxes_3d_data is not None:
-            if self.use_box_adapter:
-                raise NotImplementedError("use_box_adapter (SURVEY.md §8f N1)")
             nb = bboxes_3d_data["bboxes"].shape[1]
             flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in bboxes_3d_data.items()}
-            box = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"])
+            if self.use_box_adapter:                                # :873-878: class tokens for the adapter
+                box, cls = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"], return_cls_emb=True)
+                cls = cls.reshape(b, nb, *cls.shape[1:])
+            else:
+                box = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"])
             box = box.reshape(b, nb, *box.shape[1:])
             if nb != n_cam:
                 assert nb == 1, "either N_cam or 1."
                 box = box.expand(-1, n_cam, -1, -1)
+                cls = None if cls is None else cls.expand(-1, n_cam, -1, -1)
         m = b * n_cam
         ctx = ctx.reshape(m, ctx.shape[2], ctx.shape[3])
-        full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1007
+        full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1065-1068
         full = full.contiguous()
-        return {"ctx": full, "ctx2d": full.reshape(-1, full.shape[-1]), "lc": full.shape[1], "m": m,
-                "txt": ctx[:, 1:].contiguous()}                     # text tokens without the camera token (:977)
+        out = {"ctx": full, "ctx2d": full.reshape(-1, full.shape[-1]), "lc": full.shape[1], "m": m,
+               "txt": ctx[:, 1:].contiguous()}                      # text tokens without the camera token (:977)
+        # the ControlNet's own cross-attentions additionally see the class tokens when the adapter is on
+        # (:1006,:1021); the UNet never does (:1065-1068)
+        if cls is not None:
+            blk = torch.cat([full, cls.reshape(m, *cls.shape[2:]).to(dt)], dim=1).contiguous()
+            out.update({"ctx2d_cn": blk.reshape(-1, blk.shape[-1]), "lc_cn": blk.shape[1]})
+            nbox = box.shape[2]
+            for proc in self.attn_processors.values():              # :898-900
+                if isinstance(proc, Adapter_XFormersAttnProcessor):
+                    proc.num_tokens = nbox
+        return out
 
     def prepare_cond(self, tok, controlnet_cond):
         """Condition-image half (:967-988): embed the ORS condition (or take the ORS-3D volume), SFA."""
@@ -309,7 +322,7 @@ class BEVControlNetModel(ModelBase):
         place — the dual-branch sum of pipeline_bev_controlnet.py:421-429 without extra passes."""
         dt = self.dtype
         assert not self.use_cam_in_temb, "not available now (:954)"
-        ctx2d, lc = prep["ctx2d"], prep["lc"]
+        ctx2d, lc = prep.get("ctx2d_cn", prep["ctx2d"]), prep.get("lc_cn", prep["lc"])
         if self.prefetch_kv:
             if self.__dict__.get("_kv_stream") is None:
                 self.__dict__["_kv_stream"] = torch.cuda.Stream()

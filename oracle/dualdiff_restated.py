@@ -142,7 +142,7 @@ class BBoxEmbedder(nn.Module):
         e = F.silu(self.bbox_proj(pos_emb))
         return self.second_linear(torch.cat([e, cls_emb], dim=-1))
 
-    def forward(self, bboxes, classes, masks=None):
+    def forward(self, bboxes, classes, masks=None, return_cls_emb=False):
         b, n = classes.shape
         pts = bboxes.reshape(b * n, -1, 3)
         m = torch.ones(b * n) if masks is None else masks.reshape(-1)
@@ -151,7 +151,58 @@ class BBoxEmbedder(nn.Module):
         pos = pos * m + self.null_pos_feature[None] * (1 - m)
         cls = self._class_tokens[classes.reshape(-1)]
         cls = cls * m + self.null_class_feature[None] * (1 - m)
-        return self.forward_feature(pos, cls).reshape(b, n, -1)
+        emb = self.forward_feature(pos, cls).reshape(b, n, -1)
+        if return_cls_emb:                                                  # :199-203
+            return emb, cls.reshape(b, n, -1)
+        return emb
+
+
+# ----------------------------------------------------------- box / class adapter (N1) --
+class AdapterAttnProcessor(nn.Module):
+    """networks/box_adapter.py:177-411 `Adapter_XFormersAttnProcessor`: the context is
+    [text(+cam) | box tokens | class tokens]; the text part feeds the layer's own K/V; the box tokens
+    get their own K/V projections, each enriched by an attention over the class tokens' K/V
+    (:349-357), and a second attention of the SAME queries over them is added with `scale` (:380-388)
+    before the out-projection."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, scale=1.0, num_tokens=200):
+        super().__init__()
+        self.scale, self.num_tokens = scale, num_tokens
+        d = cross_attention_dim or hidden_size
+        self.to_k_box = nn.Linear(d, hidden_size, bias=False)
+        self.to_v_box = nn.Linear(d, hidden_size, bias=False)
+        self.to_k_cls = nn.Linear(d, hidden_size, bias=False)
+        self.to_v_cls = nn.Linear(d, hidden_size, bias=False)
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+        assert attention_mask is None and encoder_hidden_states is not None
+        q = attn.to_q(hidden_states)
+        e = encoder_hidden_states
+        end = e.shape[1] - self.num_tokens                                   # :276-284
+        e, cls_h = e[:, :end], e[:, end:]
+        end = e.shape[1] - self.num_tokens
+        e, box_h = e[:, :end], e[:, end:]
+        out = sdpa(q, attn.to_k(e), attn.to_v(e), attn.heads, attn.scale)    # :291-292,:339-341
+        bk, bv = self.to_k_box(box_h), self.to_v_box(box_h)                  # :294-298
+        ck, cv = self.to_k_cls(cls_h), self.to_v_cls(cls_h)
+        bk = bk + sdpa(bk, ck, cv, attn.heads, attn.scale)                   # :349-353
+        bv = bv + sdpa(bv, ck, cv, attn.heads, attn.scale)                   # :354-357
+        out = out + self.scale * sdpa(q, bk, bv, attn.heads, attn.scale)     # :380-388
+        return attn.to_out[0](out)                                           # :391
+
+
+def box_adapter(net):
+    """networks/box_adapter.py:414-444 (use_box_token False): the adapter on every text cross-attention
+    (attn2), initialised from that layer's own to_k / to_v; plain processors elsewhere."""
+    sd = net.state_dict()
+    for name, m in [(n, mm) for n, mm in net.named_modules() if hasattr(mm, "set_processor")]:
+        if name.endswith("attn1") or name.endswith("attn4"):
+            continue
+        p = AdapterAttnProcessor(hidden_size=m.to_q.out_features, cross_attention_dim=m.to_k.in_features)
+        p.load_state_dict({"to_k_box.weight": sd[name + ".to_k.weight"], "to_v_box.weight": sd[name + ".to_v.weight"],
+                           "to_k_cls.weight": sd[name + ".to_k.weight"], "to_v_cls.weight": sd[name + ".to_v.weight"]})
+        m.set_processor(p)          # an nn.Module processor becomes the sub-module `<attn>.processor`
+    return net
 
 
 # -------------------------------------------------------------- multiview block (A4, A6) --
@@ -279,11 +330,23 @@ class BEVControlNetModel(D.ModelMixin):
             bb = bboxes_3d_data["bboxes"]
             nb = bb.shape[1]
             flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in bboxes_3d_data.items()}
-            box = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"])
+            cls = None
+            if getattr(self, "use_box_adapter", False):                                   # :873-878
+                box, cls = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"], return_cls_emb=True)
+                cls = cls.reshape(b, nb, *cls.shape[1:])
+            else:
+                box = self.bbox_embedder(flat["bboxes"], flat["classes"], flat["masks"])
             box = box.reshape(b, nb, *box.shape[1:])
             if nb != n_cam:
                 box = box.expand(-1, n_cam, -1, -1)
+                cls = None if cls is None else cls.expand(-1, n_cam, -1, -1)
             box = box.reshape(b * n_cam, *box.shape[2:])
+            cls = None if cls is None else cls.reshape(b * n_cam, *cls.shape[2:])
+            for m in self.modules():                                                      # :898-900
+                if isinstance(getattr(m, "processor", None), AdapterAttnProcessor):
+                    m.processor.num_tokens = box.shape[1]
+        else:
+            cls = None
         t = timestep.reshape(-1)
         emb = self.time_embedding(self.time_proj(t).to(self.dtype))                       # :921-929
         x = sample.reshape(b * n_cam, *sample.shape[2:])
@@ -294,15 +357,16 @@ class BEVControlNetModel(D.ModelMixin):
         if self.use_txt_con_fusion:
             cond = self.txt_con_fusion(cond, ctx[:, 1:])                                  # :973-978 (no cam token)
         x = x + cond                                                                      # :990
-        full_ctx = ctx if box is None else torch.cat([ctx, box], dim=1)                   # :1007
+        full_ctx = ctx if box is None else torch.cat([ctx, box], dim=1)                   # :1065-1068
+        blk_ctx = full_ctx if cls is None else torch.cat([full_ctx, cls], dim=1)          # :1006,:1021 (+ class tokens)
         skips = (x,)
         for blk in self.down_blocks:
             if getattr(blk, "has_cross_attention", False):
-                x, res = blk(hidden_states=x, temb=emb, encoder_hidden_states=full_ctx)
+                x, res = blk(hidden_states=x, temb=emb, encoder_hidden_states=blk_ctx)
             else:
                 x, res = blk(hidden_states=x, temb=emb)
             skips += res
-        x = self.mid_block(x, emb, encoder_hidden_states=full_ctx)
+        x = self.mid_block(x, emb, encoder_hidden_states=blk_ctx)
         down = [zc(s) * conditioning_scale for s, zc in zip(skips, self.controlnet_down_blocks)]   # :1031-1054
         mid = self.controlnet_mid_block(x) * conditioning_scale                           # :1039,:1055
         return down, mid, full_ctx                                                        # :1066-1076

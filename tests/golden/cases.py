@@ -38,6 +38,14 @@ def proc_inputs():
     return seeded_tensor((3, 140, 320), 105), seeded_tensor((3, 13, 768), 106)
 
 
+def adapter_inputs():
+    """hidden (3, 140, 320); context = 13 text(+cam) tokens | 5 box tokens | 5 class tokens."""
+    return seeded_tensor((3, 140, 320), 115), seeded_tensor((3, 13 + 5 + 5, 768), 116), 5
+
+
+SEED_ADAPTER = 21
+
+
 def block_kwargs():
     return dict(dim=64, num_attention_heads=8, attention_head_dim=8, cross_attention_dim=48)
 

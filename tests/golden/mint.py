@@ -13,9 +13,9 @@ copied):
 
 Consequences for pinning (DESIGN.md "Oracle"):
   LEVEL 1 (true reference arithmetic; only the SDPA stand-in is ours):
-      sfa, sfa_plus, cond_embedder, bbox_embedder, attn_processor
+      sfa, sfa_plus, cond_embedder, bbox_embedder, attn_processor, adapter_processor
   LEVEL 2 (reference control flow executed verbatim over our restated leaf modules):
-      multiview_block, unet_multiview, controlnet_bg, controlnet_fg
+      multiview_block, unet_multiview, controlnet_bg, controlnet_fg, controlnet_bg_adapter
 
 Usage:  python tests/golden/mint.py      (rewrites tests/golden/*.npz)
 """
@@ -137,6 +137,15 @@ def main():
     save("attn_processor", out=ref_proc.XFormersAttnProcessor()._real_call(attn, h, ctx),
          out_self=ref_proc.XFormersAttnProcessor()._real_call(_self_attn(), h))
 
+    # ---- L1: box / class adapter processor (N1, box_adapter.py:177-411) --------------------
+    attn = D.Attention(query_dim=320, cross_attention_dim=768, heads=8, dim_head=40)
+    attn.load_state_dict(seeded_state_dict(attn, C.SEED_PROC))
+    ref = ref_proc.Adapter_XFormersAttnProcessor(hidden_size=320, cross_attention_dim=768, scale=0.7)
+    load_from(ref, R.AdapterAttnProcessor(320, 768), C.SEED_ADAPTER)
+    h, ctx, nt = C.adapter_inputs()
+    ref.num_tokens = nt
+    save("adapter_processor", out=ref._real_call(attn, h, ctx))
+
     # ---- L2: multiview transformer block ---------------------------------------------------
     kw = C.block_kwargs()
     ref = ref_blocks.BasicMultiviewTransformerBlock(**kw, neighboring_view_pair=C.VIEW_PAIR)
@@ -190,6 +199,17 @@ def main():
                              use_aug_text=False)
         arrays = {"down_%d" % i: d for i, d in enumerate(down)}
         save(name, mid=mid, ctx=ctx, **arrays)
+        if not occ3d:
+            # same branch with the box / class adapter installed by the reference's own installer
+            # (box_adapter.py:414-444) and `use_box_adapter` poked like multiview_runner.py:191,241-242
+            ref.use_box_adapter = True
+            ref_proc.box_adapter(ref)
+            down, mid, ctx = ref(inp["sample"], inp["timestep"], inp["camera_param"], inp["bboxes_3d_data"],
+                                 inp["encoder_hidden_states"], inp["controlnet_cond"],
+                                 conditioning_scale=inp["conditioning_scale"], return_dict=False,
+                                 use_aug_text=False)
+            arrays = {"down_%d" % i: d for i, d in enumerate(down)}
+            save(name + "_adapter", mid=mid, ctx=ctx, **arrays)
 
 
 def _self_attn():

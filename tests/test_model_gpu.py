@@ -190,6 +190,77 @@ def test_controlnet_forward(cnet_case, occ3d, dtype):
     assert max(errs) <= 1.0, rec
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_box_adapter_processor(gpu, dtype):
+    """N1: Adapter_XFormersAttnProcessor on the HIP kernels vs the oracle restatement that
+    is pinned to the reference's own `_real_call` (tests/golden/adapter_processor.npz), on the golden
+    case (3 x 140 tokens, 13 text | 5 box | 5 class tokens, scale 0.7) and at the L0 layer shape."""
+    from oracle import diffusers_restated as D
+    from oracle.init_utils import seeded_init_
+    from tests.golden import cases as C
+    from dualdiff_amd.networks.box_adapter import Adapter_XFormersAttnProcessor
+    from dualdiff_amd.networks.layers import Attention
+    for (b, lq, lt, nt, scale) in ((3, 140, 13, 5, 0.7), (12, 1400, 78, 20, 1.0)):
+        oa = seeded_init_(D.Attention(query_dim=320, cross_attention_dim=768, heads=8, dim_head=40), C.SEED_PROC)
+        op = seeded_init_(R.AdapterAttnProcessor(320, 768, scale=scale), C.SEED_ADAPTER)
+        for m in (oa, op):
+            m.load_state_dict({k: bf16_round(v) for k, v in m.state_dict().items()})
+        op.num_tokens = nt
+        h = bf16_round(seeded_tensor((b, lq, 320), 115))
+        ctx = bf16_round(seeded_tensor((b, lt + 2 * nt, 768), 116))
+        with torch.no_grad():
+            ref = op(oa, h, ctx)
+        a = Attention(320, 768, 8, 40)
+        a.load_state_dict(oa.state_dict())
+        p = Adapter_XFormersAttnProcessor(320, 768, scale=scale)
+        p.load_state_dict(op.state_dict())
+        a.set_processor(p)
+        a = a.to("cuda", dtype).eval()
+        p.num_tokens = nt
+        with torch.no_grad():
+            out = a(h.cuda().to(dtype), encoder_hidden_states=ctx.cuda().to(dtype))
+        e = rel_l2(out, ref)
+        print("adapter processor b=%d lq=%d nt=%d %s: rel-L2 %.3e" % (b, lq, nt, dtype, e))
+        assert out.shape == ref.shape and e <= (2e-3 if dtype == torch.float16 else 8e-3), e
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_controlnet_forward_box_adapter(cnet_case, dtype):
+    """N1: ControlNet branch with use_box_adapter + the box_adapter() installer: class tokens reach the
+    ControlNet's cross-attentions only; the tokens handed to the UNet stay [cam | text | box]."""
+    from dualdiff_amd.networks.box_adapter import Adapter_XFormersAttnProcessor, box_adapter
+    inp, refs = cnet_case
+    sd = refs[False][0]
+    ora = R.BEVControlNetModel(use_occ_3d=False).eval()
+    ora.load_state_dict(sd)
+    ora.use_box_adapter = True
+    R.box_adapter(ora)
+    def run():
+        return ora(inp["sample"], inp["timestep"], inp["camera_param"], inp["boxes_bg"], inp["text"],
+                   inp["cond_bg"], conditioning_scale=0.75)
+    with torch.no_grad():
+        rdown, rmid, rctx = run()
+        with storage_emulation(ora, dtype):
+            edown, emid, ectx = run()
+    net = _make_cnet(sd, False, dtype)
+    net.use_box_adapter = True
+    box_adapter(net)
+    assert sum(isinstance(p, Adapter_XFormersAttnProcessor) for p in net.attn_processors.values()) == 7
+    assert any(k.endswith("attn2.processor.to_k_box.weight") for k in net.state_dict())
+    d = _to_dev(inp, dtype)
+    with torch.no_grad():
+        down, mid, ctx = net(d["sample"], d["timestep"], d["camera_param"], d["boxes_bg"], d["text"],
+                             d["cond_bg"], conditioning_scale=0.75, return_dict=False, use_aug_text=False)
+    rec = []
+    errs = [report("cnet+adapter down[%d]" % i, a, b, dtype, rec, e) for i, (a, b, e) in enumerate(zip(down, rdown, edown))]
+    errs.append(report("cnet+adapter mid", mid, rmid, dtype, rec, emid))
+    errs.append(report("cnet+adapter ctx tokens", ctx, rctx, dtype, rec, ectx))
+    assert ctx.shape[1] == 1 + LTXT + NBOX                          # no class tokens towards the UNet
+    assert max(errs) <= 1.0, rec
+    # and the adapter is live: the result differs from the plain branch
+    assert rel_l2(mid, refs[False][1][1]) > 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float16])
 def test_full_step_dual_branch_graph_vs_oracle(unet_case, cnet_case, dtype):
     """Two DDIM steps of the complete config-2 step (2 ControlNet branches, SFA on, CFG, b = 1 ->

@@ -58,6 +58,16 @@ def test_attn_processor_protocol():
 
 
 @torch.no_grad()
+def test_adapter_processor():
+    """N1: box / class adapter processor against the reference's own `_real_call` (level 1)."""
+    a = seeded_init_(D.Attention(query_dim=320, cross_attention_dim=768, heads=8, dim_head=40), C.SEED_PROC)
+    proc = seeded_init_(R.AdapterAttnProcessor(320, 768, scale=0.7), C.SEED_ADAPTER)
+    h, ctx, nt = C.adapter_inputs()
+    proc.num_tokens = nt
+    C.compare(gold("adapter_processor"), "out", proc(a, h, ctx), RTOL, ATOL)
+
+
+@torch.no_grad()
 def test_multiview_block():
     m = seeded_init_(R.BasicMultiviewTransformerBlock(**C.block_kwargs(), neighboring_view_pair=C.VIEW_PAIR),
                      C.SEED_BLOCK)
@@ -92,6 +102,28 @@ def test_controlnet(name, occ3d):
         C.compare(g, "down_%d" % i, d, 1e-3, 1e-4)
     C.compare(g, "mid", mid, 1e-3, 1e-4)
     C.compare(g, "ctx", ctx, RTOL, ATOL)
+
+
+@torch.no_grad()
+def test_controlnet_box_adapter():
+    """N1, level 2: ControlNet branch with `use_box_adapter` and the reference's own installer
+    (box_adapter.py:414-444): class tokens appended for the ControlNet's cross-attentions only, the
+    context handed to the UNet stays [cam | text | box]."""
+    m = seeded_init_(R.BEVControlNetModel(**C.controlnet_oracle_kwargs(), use_occ_3d=False), C.SEED_CNET).eval()
+    m.use_box_adapter = True
+    R.box_adapter(m)
+    inp = C.controlnet_inputs(False)
+    down, mid, ctx = m(inp["sample"], inp["timestep"], inp["camera_param"], inp["bboxes_3d_data"],
+                       inp["encoder_hidden_states"], inp["controlnet_cond"],
+                       conditioning_scale=inp["conditioning_scale"])
+    g = gold("controlnet_bg_adapter")
+    for i, d in enumerate(down):
+        C.compare(g, "down_%d" % i, d, 1e-3, 1e-4)
+    C.compare(g, "mid", mid, 1e-3, 1e-4)
+    C.compare(g, "ctx", ctx, RTOL, ATOL)
+    # the adapter must actually change the result (guards against a silently inactive installer)
+    g0 = gold("controlnet_bg")
+    assert not np.allclose(g["mid" if "mid" in g.files else g.files[0]], g0["mid" if "mid" in g0.files else g0.files[0]])
 
 
 def test_state_dict_contract_sd15():
