@@ -191,6 +191,32 @@ def test_controlnet_forward(cnet_case, occ3d, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("plus", [False, True], ids=["sfa", "sfa_plus"])
+@pytest.mark.parametrize("m", [6, 48], ids=["golden_case", "config3_batch4"])
+def test_sfa_standalone(gpu, plus, m, dtype):
+    """A12 / A13 standalone (BASELINE config 3: batch 4 scenes -> 48 view-instances): SFA and SFA+ on
+    the HIP kernels vs the oracle restatement that is pinned to the reference's own modules
+    (tests/golden/sfa*.npz); NCHW in / NCHW out like unet_addon_rawbox.py:974-978 calls it."""
+    from oracle.init_utils import seeded_init_
+    from tests.golden import cases as C
+    from dualdiff_amd.networks.txt_con_fusion import txt_con_XFormersAttn, txt_con_XFormersAttn_plus
+    ora = seeded_init_((R.TxtConFusionPlus if plus else R.TxtConFusion)(), C.SEED_SFA)
+    ora.load_state_dict({k: bf16_round(v) for k, v in ora.state_dict().items()})
+    x = bf16_round(seeded_tensor((m, 320, H, W), 101))
+    e = bf16_round(seeded_tensor((m, 77, 768), 102))
+    with torch.no_grad():
+        ref = ora(x, e)
+    net = (txt_con_XFormersAttn_plus if plus else txt_con_XFormersAttn)()
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net = net.to("cuda", dtype).eval()
+    with torch.no_grad():
+        out = net(attn=None, hidden_states=x.cuda().to(dtype), encoder_hidden_states=e.cuda().to(dtype))
+    err = rel_l2(out, ref)
+    print("SFA%s m=%d %s: rel-L2 %.3e" % ("+" if plus else "", m, dtype, err))
+    assert out.shape == ref.shape and err <= (1e-3 if dtype == torch.float16 else 8e-3), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_box_adapter_processor(gpu, dtype):
     """N1: Adapter_XFormersAttnProcessor on the HIP kernels vs the oracle restatement that
     is pinned to the reference's own `_real_call` (tests/golden/adapter_processor.npz), on the golden
