@@ -311,6 +311,12 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
   if (variant == 1) {
     return qt2 ? launch_attn<T, D, 2, false, 64>(p, s) : launch_attn<T, D, 1, false, 64>(p, s);
   }
+  // variants 2..4: explicit (rows per wave, key tile) choices for tuning experiments
+  if (variant == 2) { if constexpr (D <= 80) return launch_attn<T, D, 1, true, 128>(p, s); }
+  if (variant == 3) return launch_attn<T, D, 2, true, 64>(p, s);
+  if (variant == 4) return launch_attn<T, D, 1, true, 64>(p, s);
+  // (d = 40 with 16 rows per wave x 64-key tiles is 5-7 % faster back-to-back, tools/attn_variants.py,
+  //  but neutral inside the step; the default stays 32 rows x 128 keys)
   if constexpr (D <= 80) {
     if (p.lk >= 512) return qt2 ? launch_attn<T, D, 2, true, 128>(p, s) : launch_attn<T, D, 1, true, 128>(p, s);
   }
