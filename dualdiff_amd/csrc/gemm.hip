@@ -38,6 +38,7 @@ struct GemmParams {
   uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
   int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
+  int* tile_counters;                    // split-K: per-tile arrival counters (in-kernel ordered reduction) or NULL
 };
 
 // --- epilogue on 8 consecutive output channels of one row --------------------------------
@@ -96,7 +97,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <typename T, int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
                                            int block_n0, int wave_m, int wave_n, int lane, int row_end,
-                                           const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
+                                           const float* ln_mean = nullptr, const float* ln_rstd = nullptr,
+                                           int tile_id = 0) {
   const int q = lane >> 4;
   const int c = lane & 15;
   const int row0 = block_m0 + wave_m * (TM * 16) + c;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
   } else {
     constexpr int NG = TN / 2;
     const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
-    if (p.partial) {                       // split-K slab: plain fp32 stores, the reduce kernel runs the epilogue
+    if (p.partial) {                       // split-K slab: plain fp32 stores
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int row = row0 + tm * 16;
@@ -182,7 +184,41 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
           *reinterpret_cast<f32x4*>(dst + 4) = acc[g8 * 2 + 1][tm];
         }
       }
-      return;
+      if (!p.tile_counters) return;        // two-launch mode: dd_splitk_reduce_kernel runs the epilogue
+      // In-kernel ORDERED reduction: the K-slice that arrives last at the tile's counter adds all the
+      // slabs in slice order (bit-reproducible, whoever is last) and runs the epilogue — no second
+      // launch.  The slabs of one tile are written from different XCDs whose L2s are not coherent
+      // with each other: device-scope release (L2 write-back) before the counter, acquire
+      // (invalidate) after it.
+      __shared__ int s_last;
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int prev = atomicAdd(p.tile_counters + tile_id, 1);
+        s_last = prev == (int)gridDim.z - 1;
+        if (s_last) p.tile_counters[tile_id] = 0;      // ready for the next launch (stream-ordered)
+      }
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int rowc = min(row0 + tm * 16, p.rows - 1);
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8) {
+          const int colc = min(col0 + g8 * 8, p.n - 8);
+          f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+          for (int z = 0; z < (int)gridDim.z; ++z) {
+            const float* src = p.partial + ((int64_t)z * p.rows + rowc) * p.n + colc;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+            s0[0] += a[0]; s0[1] += a[1]; s0[2] += a[2]; s0[3] += a[3];
+            s1[0] += b[0]; s1[1] += b[1]; s1[2] += b[2]; s1[3] += b[3];
+          }
+          acc[g8 * 2][tm] = s0;
+          acc[g8 * 2 + 1][tm] = s1;
+        }
+      }
     }
     // Rows are handled in (at most) two batches: per batch, phase 1 issues ALL its loads (clamped
     // addresses, nothing predicated), phase 2 does the arithmetic and the stores.  One batch would
@@ -469,7 +505,7 @@ void dd_gemm_kernel(const GemmParams p) {
     buf ^= 1;
   }
 
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile);
 }
 
 // =============================================================================================
@@ -753,7 +789,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   }
   const bool ln = !CONV && p.ln_colsum;
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
-                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr);
+                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr, tile);
 }
 
 // =============================================================================================
@@ -942,7 +978,8 @@ void dd_conv3s_kernel(const GemmParams p) {
     }
   }
   // rows past the tile's instances are padding
-  store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows));
+  store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows),
+                               nullptr, nullptr, tile);
 }
 
 // split-K: sum the fp32 partial slabs and run the fused epilogue.
@@ -1203,7 +1240,7 @@ int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hip
     rc = launch_tile<T, false, false>(p, pl, s);
   }
   if (rc != DD_OK) return rc;
-  if (pl.split > 1) {
+  if (pl.split > 1 && !p.tile_counters) {
     const int64_t total = (int64_t)p.rows * (p.n / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1254,11 +1291,22 @@ thread_local char g_kname[160];
 extern "C" int dd_gemm_num_tiles(void) { return kNumTiles; }
 extern "C" int dd_gemm_tile_id(int index) { return (index >= 0 && index < kNumTiles) ? kTiles[index].id : -1; }
 
+// Split-K workspace layout: [DD_COUNTER_BYTES of per-tile arrival counters][split fp32 slabs].  The
+// counter region must be zero when the workspace is first handed in; every launch leaves it zero.
+constexpr int64_t DD_COUNTER_BYTES = 65536;
+// In-kernel reduction is OFF by default: the device-scope release / acquire it needs (the L2s of the
+// 8 XCDs are not coherent: buffer_wbl2 + buffer_inv per workgroup) costs far more than the second
+// launch — 4x7 conv 32 -> 66 us, whole step 73.5 -> 69.1 steps/s.  DD_SPLITK_INKERNEL=1 enables it.
+bool inkernel_reduce(const Plan& pl) {
+  static const bool on = getenv("DD_SPLITK_INKERNEL") && atoi(getenv("DD_SPLITK_INKERNEL")) == 1;
+  return on && (int64_t)pl.tiles_m * pl.tiles_n * (int64_t)sizeof(int) <= DD_COUNTER_BYTES;
+}
+
 extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
   if (validate(d) != DD_OK) return 0;
   const Plan pl = make_plan(d);
   if (pl.unsupported || pl.split <= 1) return 0;
-  return (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
+  return DD_COUNTER_BYTES + (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
 }
 
 extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
@@ -1319,10 +1367,12 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
     }
   }
   p.partial = nullptr;
+  p.tile_counters = nullptr;
   if (pl.split > 1) {
-    const int64_t need = (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
+    const int64_t need = DD_COUNTER_BYTES + (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
     if (!d->ws || d->ws_bytes < need) return DD_ERR_WORKSPACE;
-    p.partial = reinterpret_cast<float*>(d->ws);
+    p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ws) + DD_COUNTER_BYTES);
+    if (inkernel_reduce(pl)) p.tile_counters = reinterpret_cast<int*>(d->ws);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();

@@ -198,18 +198,19 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def workspace(nbytes, device):
-    """Grow-only fp32 scratch buffer per (device, stream): kernels on concurrent streams must not
-    share split-K / GroupNorm scratch.  Allocate before graph capture (eager warm-up)."""
+def workspace(nbytes, device, kind="gemm"):
+    """Grow-only fp32 scratch buffer per (device, stream, kind): kernels on concurrent streams must
+    not share scratch, and the split-K buffer (whose leading counter region dd_gemm keeps at zero)
+    is never lent to GroupNorm.  Zero-filled on allocation; allocate before graph capture."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+           torch.cuda.current_stream().cuda_stream, kind)
     ws = _WS.get(key)
     need = max(int(nbytes), _WS_MIN_BYTES)
     if ws is None or ws.numel() * 4 < need:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("workspace would have to grow during graph capture; run one eager "
                                "warm-up step first")
-        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
 
@@ -359,7 +360,7 @@ def groupnorm(x, gamma, beta, m, hw, groups, eps, silu, x2=None, out=None):
     if out is None:
         out = torch.empty((m * hw, c1 + c2), dtype=x.dtype, device=x.device)
     need = lib.dd_groupnorm_workspace_bytes(m, groups)
-    ws = workspace(need, x.device)
+    ws = workspace(need, x.device, "gn")
     rc = lib.dd_groupnorm_nhwc(_ptr(x), c1, _ptr(x2), c2, _ptr(gamma), _ptr(beta), _ptr(out),
                                m, hw, groups, eps, int(silu), _dt(x), _ptr(ws), ws.numel() * 4,
                                _stream())

@@ -104,7 +104,10 @@ typedef struct dd_gemm_desc {
   int32_t dtype;       /* DD_F16 / DD_BF16 */
   int32_t tile;        /* 0 = auto, else tile-config id (see dd_gemm_num_tiles) */
   int32_t split_k;     /* 0 = auto, 1 = off, >1 = number of K slices */
-  void* ws;            /* fp32 workspace for split-K partials */
+  void* ws;            /* split-K workspace (>= dd_gemm_workspace_bytes): 64 KiB of per-tile arrival
+                          counters, then the fp32 partial slabs.  The counter region must be ZERO the
+                          first time a buffer is handed in; every call leaves it zero, so one buffer
+                          serves all launches of a stream.  Nothing else may write to it. */
   int64_t ws_bytes;
   /* LayerNorm fold (dense mode, K in {320, 640, 1280}, no a2, no split-K): `a` holds the
    * UN-normalised rows x; the kernel computes each row's mean / rstd over its K columns in its
