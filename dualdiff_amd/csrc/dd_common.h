@@ -61,18 +61,21 @@ __device__ __forceinline__ u32x4 dd_pack8(const float (&f)[8]) {
   return dd_as_u4<T>(v);
 }
 
-__device__ __forceinline__ float dd_silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + the 1-ulp v_rcp_f32 (a true division costs a ~10-instruction fix-up chain)
+__device__ __forceinline__ float dd_silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16/bf16 resolution): one rcp, one
 // exp and five fmas instead of libm's ~40-instruction erff — the GEGLU epilogue evaluates it on
 // 21.5 M gate values per L0 feed-forward.
 __device__ __forceinline__ float dd_erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // 1-ulp v_rcp_f32: no division fix-up chain
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-ax * ax);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
   const float r = 1.0f - p * t * e;
   return copysignf(r, x);
 }
