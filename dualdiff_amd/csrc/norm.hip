@@ -125,6 +125,20 @@ void dd_gn_apply_kernel(const GnParams p) {
   __shared__ float s_mean[64], s_rstd[64];
   __shared__ float s_ps[GN_THREADS], s_pq[GN_THREADS];
   const int split = blockIdx.x, inst = blockIdx.y;
+  const GnMap mp = gn_map(p.c);
+  const int p0 = split * p.pix_per_split;
+  const int p1 = min(p.hw, p0 + p.pix_per_split);
+  // The first batch of pixel vectors does not depend on the statistics: issue its loads BEFORE the
+  // partial sums are fetched and combined, so the two memory round trips overlap.
+  const int cv_first = mp.cv;
+  const int ch_first = min(cv_first, mp.cv_count - 1) << 3;
+  u32x4 pre[GN_UNROLL];
+  const bool pre_ok = mp.active && cv_first < mp.cv_count && p0 + mp.pl + (GN_UNROLL - 1) * mp.pl_count < p1;
+  if (pre_ok) {
+#pragma unroll
+    for (int u = 0; u < GN_UNROLL; ++u)
+      pre[u] = dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + p0 + mp.pl + u * mp.pl_count, ch_first));
+  }
   {
     // combine the per-split partial sums: all 256 threads fetch in parallel (chunk-strided), then
     // one thread per group adds the chunk sums in a fixed order (bit-reproducible).
@@ -153,10 +167,7 @@ void dd_gn_apply_kernel(const GnParams p) {
     }
   }
   __syncthreads();
-  const GnMap mp = gn_map(p.c);
   if (!mp.active) return;
-  const int p0 = split * p.pix_per_split;
-  const int p1 = min(p.hw, p0 + p.pix_per_split);
   for (int cv = mp.cv; cv < mp.cv_count; cv += GN_THREADS) {
     const int ch = cv << 3;
     float ga[8], be[8], sc[8], sh[8];
@@ -179,6 +190,11 @@ void dd_gn_apply_kernel(const GnParams p) {
       dd_st16(reinterpret_cast<T*>(p.y) + row * p.c + ch, dd_pack8<T>(f));
     };
     int px = p0 + mp.pl;
+    if (cv == cv_first && pre_ok) {                    // the prefetched batch
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) apply_store(pre[u], (int64_t)inst * p.hw + px + u * mp.pl_count);
+      px += GN_UNROLL * mp.pl_count;
+    }
     for (; px + (GN_UNROLL - 1) * mp.pl_count < p1; px += GN_UNROLL * mp.pl_count) {
       u32x4 v[GN_UNROLL];
 #pragma unroll
