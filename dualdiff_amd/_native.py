@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_v
 
 from . import _build
 
-DD_F16, DD_BF16 = 0, 1
+DD_F16, DD_BF16, DD_F32 = 0, 1, 2
 DD_EPI_NONE, DD_EPI_GEGLU, DD_EPI_SILU = 0, 1, 2
 
 
@@ -72,6 +72,8 @@ SIGNATURES = {
     "dd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dd_timestep_embedding": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                         c_int32, c_void_p]),
+    "dd_fourier_embed": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, POINTER(c_float), c_int32, c_int32,
+                                   c_int32, c_int32, c_void_p]),
     "dd_conv3x3_small_cout": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                         c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dd_cfg_ddim_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

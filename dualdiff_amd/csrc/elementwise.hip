@@ -81,6 +81,27 @@ void dd_timestep_embedding_kernel(const float* t, T* out, int n, int dim, int fl
   }
 }
 
+struct FourierFreqs { float f[16]; };
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256)
+void dd_fourier_embed_kernel(const TI* x, TO* out, int64_t total, int dims, FourierFreqs fr, int nf, int inc) {
+  const int width = dims * (inc + 2 * nf);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / dims;
+    const int d = (int)(i - row * dims);
+    const float v = (float)x[i];
+    TO* o = out + row * width + d;
+    if (inc) { *o = (TO)v; o += dims; }
+    for (int k = 0; k < nf; ++k) {
+      const float a = v * fr.f[k];
+      o[0] = (TO)sinf(a);
+      o[dims] = (TO)cosf(a);
+      o += 2 * dims;
+    }
+  }
+}
+
 // conv3x3 (pad 1, stride 1) with a handful of output channels: one wave per output pixel,
 // the 9*cin products are spread over the 64 lanes and reduced with shuffles.  Output NCHW.
 template <typename T, int MAXCO>
@@ -250,6 +271,36 @@ extern "C" int dd_timestep_embedding(const float* t, void* out, int32_t n, int32
     hipLaunchKernelGGL(dd_timestep_embedding_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s,
                        t, (__bf16*)out, n, dim, flip_sin_to_cos, freq_shift);
   return dd_check_launch();
+}
+
+template <typename TI>
+int launch_fourier(const void* x, void* out, int64_t total, int dims, const FourierFreqs& fr, int nf, int inc,
+                   int out_dtype, hipStream_t s) {
+  const unsigned g = (unsigned)grid_for(total > (1 << 30) ? (1 << 30) : (int)total);
+  if (out_dtype == DD_F16)
+    hipLaunchKernelGGL((dd_fourier_embed_kernel<TI, _Float16>), dim3(g), dim3(256), 0, s, (const TI*)x, (_Float16*)out, total, dims, fr, nf, inc);
+  else if (out_dtype == DD_BF16)
+    hipLaunchKernelGGL((dd_fourier_embed_kernel<TI, __bf16>), dim3(g), dim3(256), 0, s, (const TI*)x, (__bf16*)out, total, dims, fr, nf, inc);
+  else
+    hipLaunchKernelGGL((dd_fourier_embed_kernel<TI, float>), dim3(g), dim3(256), 0, s, (const TI*)x, (float*)out, total, dims, fr, nf, inc);
+  return dd_check_launch();
+}
+
+extern "C" int dd_fourier_embed(const void* x, void* out, int64_t rows, int32_t dims, const float* freqs,
+                                int32_t num_freqs, int32_t include_input, int32_t in_dtype, int32_t out_dtype,
+                                dd_stream_t stream) {
+  if (!x || !out || !freqs || rows <= 0 || dims <= 0) return DD_ERR_BAD_ARG;
+  if (num_freqs <= 0 || num_freqs > 16) return DD_ERR_UNSUPPORTED;
+  if (in_dtype < 0 || in_dtype > DD_F32 || out_dtype < 0 || out_dtype > DD_F32) return DD_ERR_BAD_ARG;
+  FourierFreqs fr{};
+  for (int i = 0; i < num_freqs; ++i) fr.f[i] = freqs[i];
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
+  const int64_t total = rows * dims;
+  const int inc = include_input ? 1 : 0;
+  if (in_dtype == DD_F16) return launch_fourier<_Float16>(x, out, total, dims, fr, num_freqs, inc, out_dtype, s);
+  if (in_dtype == DD_BF16) return launch_fourier<__bf16>(x, out, total, dims, fr, num_freqs, inc, out_dtype, s);
+  return launch_fourier<float>(x, out, total, dims, fr, num_freqs, inc, out_dtype, s);
 }
 
 extern "C" int dd_conv3x3_small_cout(const void* x, const void* w, const void* bias, void* y_nchw,

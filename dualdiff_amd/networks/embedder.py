@@ -1,6 +1,10 @@
 """NeRF-style Fourier feature embedder — mirrors magicdrive/networks/embedder.py:18-67.
-Tiny, step-invariant token preparation: plain device tensor ops."""
+Tiny token preparation: one dd_fourier_embed launch on the GPU (the sin / cos / cat
+chain of the reference is ~20 launches per call on the sampler's critical stream); plain tensor ops for
+host tensors."""
 import torch
+
+from .. import ops as O
 
 
 class Embedder:
@@ -15,6 +19,8 @@ class Embedder:
         self.out_dim = input_dims * ((1 if include_input else 0) + 2 * num_freqs)
 
     def __call__(self, inputs):
+        if inputs.is_cuda and len(self.freq_bands) <= 16 and inputs.dtype in (torch.float16, torch.bfloat16, torch.float32):
+            return O.fourier_embed(inputs, self.freq_bands, self.include_input)
         outs = [inputs] if self.include_input else []
         for f in self.freq_bands:
             outs += [torch.sin(inputs * f), torch.cos(inputs * f)]

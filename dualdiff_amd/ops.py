@@ -512,6 +512,24 @@ def cfg_ddim_step(eps, x, coef, guidance, x_out=None, x_dup=None):
     return x_out
 
 
+def fourier_embed(x, freqs, include_input=True):
+    """[x, sin(f0 x), cos(f0 x), ...] on the last dim (networks/embedder.py), one kernel."""
+    lib = _native.load()
+    _need_gpu(x)
+    code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(x.dtype)
+    if code is None:
+        raise TypeError("fourier_embed takes fp16 / bf16 / fp32 tensors, got %s" % x.dtype)
+    x = x.contiguous()
+    dims = x.shape[-1]
+    rows = x.numel() // dims
+    nf = len(freqs)
+    out = torch.empty(x.shape[:-1] + (dims * ((1 if include_input else 0) + 2 * nf),), dtype=x.dtype, device=x.device)
+    arr = (ctypes.c_float * nf)(*[float(f) for f in freqs])
+    _native.check(lib.dd_fourier_embed(_ptr(x), _ptr(out), rows, dims, arr, nf, int(include_input), code, code,
+                                       _stream()), "fourier_embed")
+    return out
+
+
 def gemm_kernel_name(rows, n, k, dtype=torch.bfloat16, conv=False, cin=0, hw=(0, 0)):
     """Name/plan string of the kernel dd_gemm picks for a shape (profile matching)."""
     lib = _native.load()

@@ -205,6 +205,16 @@ int dd_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
                           int32_t flip_sin_to_cos, float freq_shift,
                           int32_t dtype, dd_stream_t stream);
 
+/* NeRF-style Fourier features (networks/embedder.py:18-67, used by the camera and 3-D box token
+ * embedders, unet_addon_rawbox.py:308-325, bbox_embedder.py:187): for every row of `dims` inputs
+ *   out[r] = [x (if include_input), sin(f_0 x), cos(f_0 x), ..., sin(f_{F-1} x), cos(f_{F-1} x)],
+ * each block `dims` wide.  x: fp32 / fp16 / bf16 per `in_dtype` (DD_F16, DD_BF16 or DD_F32); the
+ * arithmetic is fp32; out in `out_dtype`.  freqs: HOST array of num_freqs (<= 16) frequencies. */
+#define DD_F32 2
+int dd_fourier_embed(const void* x, void* out, int64_t rows, int32_t dims, const float* freqs,
+                     int32_t num_freqs, int32_t include_input, int32_t in_dtype, int32_t out_dtype,
+                     dd_stream_t stream);
+
 /* conv3x3 with tiny Cout (conv_out 320->4): y NCHW fp32/T. x NHWC (rows, cin),
  * w [cout][9*cin]; writes y as NCHW (m, cout, h, w) in dtype T.
  * (networks/unet_2d_condition_multiview.py:522) */

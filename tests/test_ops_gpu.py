@@ -306,6 +306,25 @@ def test_conv_out_small(ops, dtype):
     check(y, ref, dtype, "conv_out 320->4 (NCHW out)")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,nf,inc", [((12, 6, 7, 3), 4, True), ((60, 8, 3), 4, True), ((5, 3), 8, False)])
+def test_fourier_embed(ops, dtype, shape, nf, inc):
+    """dd_fourier_embed vs the Embedder of the reference (networks/embedder.py:18-67): block order
+    [x | sin f0 | cos f0 | ...], arithmetic in fp32, camera / box coordinate magnitudes."""
+    x = (rnd(shape, torch.float32, 1) * 30.0).to(dtype)
+    freqs = [2.0 ** i for i in range(nf)]
+    y = ops.fourier_embed(x, freqs, inc)
+    xf = x.float().cpu()
+    outs = [xf] if inc else []
+    for f in freqs:
+        outs += [torch.sin(xf * f), torch.cos(xf * f)]
+    ref = torch.cat(outs, dim=-1)
+    assert y.shape == ref.shape and y.dtype == dtype
+    tol = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    scale = ref.abs().max().item()
+    assert (y.float().cpu() - ref).abs().max().item() <= tol * max(scale, 1.0)
+
+
 # ----------------------------------------------------------------------------- norms ----
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m,hw,c1,c2,silu,eps", [
