@@ -203,12 +203,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
                          "there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DD_BENCH_SHARE_GPU=1 + DD_BENCH_BACKEND=gloo: plumbing test of the N > 1 path on a 1-GPU box
+    # (all ranks on cuda:0, bookkeeping collectives over gloo) — never a measurement.
+    share = os.environ.get("DD_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
 
     from dualdiff_amd import ops as O
@@ -249,7 +257,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         from dualdiff_amd.parallel import max_over_ranks
-        elapsed = max_over_ranks(elapsed, device)          # slowest rank sets the job's wall time
+        elapsed = max_over_ranks(elapsed, device if backend == "nccl" else None)   # slowest rank sets the job's wall time
         finite = bool(torch.isfinite(den.latents.float()).all().item())
 
         roofline = None
