@@ -121,25 +121,31 @@ class BEVDenoiser:
             if self._side is None:
                 self._side = [torch.cuda.Stream() for _ in range(n)]
             # branch 0's TOKENS feed the UNet: only they are prepared on the main stream; the condition
-            # image embedding + SFA of every branch run on the branch's own stream
+            # image embedding + SFA of every branch run on the branch's own stream.  Branches that do not
+            # feed the UNet fork first (they need nothing from the main stream but the latents).
+            results = [None] * n
+
+            def run_branch(i, p_tok=None):
+                cn, s = self.controlnets[i], self._side[i]
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    if self._prepared is not None:
+                        p_i = self._prepared[i]
+                    elif p_tok is not None:
+                        p_i = cn.prepare_cond(p_tok, self.conds[i])
+                    else:
+                        p_i = cn.prepare_condition(self.camera_param, self.bboxes_list[i], self.prompt_embeds,
+                                                   self.conds[i], self.use_aug_text)
+                    results[i] = cn.forward_nhwc(x8, m, h, w, self.t_dev, p_i, self.conditioning_scale)
+
+            for i in range(1, n):                                        # fork the independent branches
+                run_branch(i)
             if self._prepared is not None:
                 tok0 = self._prepared[0]
             else:
                 tok0 = self.controlnets[0].prepare_tokens(self.camera_param, self.bboxes_list[0],
                                                           self.prompt_embeds, self.use_aug_text)
-            results = [None] * n
-            for i, cn in enumerate(self.controlnets):                    # fork
-                s = self._side[i]
-                s.wait_stream(main)
-                with torch.cuda.stream(s):
-                    if self._prepared is not None:
-                        p_i = self._prepared[i]
-                    elif i == 0:
-                        p_i = cn.prepare_cond(tok0, self.conds[0])
-                    else:
-                        p_i = cn.prepare_condition(self.camera_param, self.bboxes_list[i], self.prompt_embeds,
-                                                   self.conds[i], self.use_aug_text)
-                    results[i] = cn.forward_nhwc(x8, m, h, w, self.t_dev, p_i, self.conditioning_scale)
+            run_branch(0, tok0)                                          # fork branch 0 once its tokens exist
             prep0 = tok0
             state = self.unet.encode_nhwc(x8, m, h, w, self.t_dev, prep0["ctx2d"], prep0["lc"])
             for s in self._side:                                         # join
