@@ -193,6 +193,10 @@ def main():
                     help="run ControlNet branches and the UNet encoder on one stream (default: 3 streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--parallelism", default="scenes", choices=["scenes", "cfg-split"],
+                    help="scenes: every rank denoises its own scene(s), no data-path collective (default, weak "
+                         "scaling); cfg-split: rank pairs share a scene, one CFG half each, and all-gather the "
+                         "noise prediction every step (single-scene latency mode, needs an even --gpus)")
     ap.add_argument("--tune-cache", default=os.environ.get("DD_TUNE_CACHE"),
                     help="load the tile/split-K table from this file if present, write it after warm-up")
     args = ap.parse_args()
@@ -225,12 +229,21 @@ def main():
     if args.tune_cache and os.path.exists(args.tune_cache):
         O.load_tuned(args.tune_cache)
     unet, cns = build_models(dtype, device)
+    cfg_kw = {}
+    pairs = 1
+    if args.parallelism == "cfg-split":
+        if dist is None or world % 2:
+            raise SystemExit("--parallelism cfg-split needs an even number of ranks (>= 2)")
+        from dualdiff_amd.parallel import cfg_all_gather, cfg_pair_groups
+        my_group = cfg_pair_groups(world)[rank // 2]
+        cfg_kw = {"cfg_half": rank % 2, "cfg_exchange": lambda e: cfg_all_gather(e, my_group)}
+        pairs = 2
     den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
                       hoist_invariant=args.hoist_invariant, use_graph=not args.no_graph,
-                      parallel_branches=not args.serial_branches)
+                      parallel_branches=not args.serial_branches, **cfg_kw)
     graph_ok = not args.no_graph
     with torch.no_grad():
-        den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank))
+        den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank // pairs))
         if graph_ok:
             try:
                 den.capture()
@@ -238,7 +251,7 @@ def main():
                 print("[bench] HIP-graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
                 den.use_graph = False
                 graph_ok = False
-                den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank))
+                den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank // pairs))
 
         def barrier():
             torch.cuda.synchronize()
@@ -303,19 +316,20 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
-    scenes_total = args.scenes * world
+    scenes_total = args.scenes * world // pairs
     steps_total = args.steps * scenes_total
     value = steps_total / elapsed
     step_tflop = (12 * GF_UNET + 24 * GF_CNET) / 1e3
     out = {
         "metric": _metric_name(),
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3 / args.scenes, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3 / args.scenes, "higher_is_better": True, "scaling": "weak" if pairs == 1 else "strong",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 6-view 224x400 (28x50 latents) multiview UNet + 2 ControlNet "
                                "branches (ORS panorama + ORS-3D, SFA on), CFG 2.0 -> 12 view-instances/scene, "
                                "DDIM-50 schedule, random-init weights",
-                   "scenes_per_gpu": args.scenes, "parallelism": "scene-sharded x%d (no data-path collective)" % world,
+                   "scenes_per_gpu": args.scenes, "parallelism": ("scene-sharded x%d (no data-path collective)" % world) if pairs == 1 else
+                                  ("CFG halves split over rank pairs x%d (all-gather of the noise prediction per step)" % (world // 2)),
                    "hip_graph": graph_ok, "streams": 1 if args.serial_branches else 3, "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
                    "algorithmic_tflop_per_step": step_tflop},
         "model_tflops": value * step_tflop,

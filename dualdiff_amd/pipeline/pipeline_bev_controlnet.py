@@ -47,7 +47,7 @@ class BEVDenoiser:
 
     def __init__(self, unet, controlnets: List, guidance_scale=2.0, num_inference_steps=50,
                  conditioning_scale=1.0, hoist_invariant=False, use_graph=True, use_aug_text=False,
-                 parallel_branches=True):
+                 parallel_branches=True, cfg_half: Optional[int] = None, cfg_exchange=None):
         self.unet = unet
         self.controlnets = list(controlnets)
         self.guidance_scale = float(guidance_scale)
@@ -64,6 +64,15 @@ class BEVDenoiser:
         # the captured graph) so the small deep-level kernels of one fill the CUs the others leave idle.
         self.parallel_branches = parallel_branches
         self._side = None
+        # CFG split: this denoiser runs only the unconditional (0) or conditional (1) half
+        # of every scene; after the model part of a step `cfg_exchange(eps_half)` must return both
+        # halves as (2, b*n, 4, h, w) in [uncond, cond] order (dualdiff_amd.parallel.cfg_all_gather).
+        if cfg_half is not None and cfg_half not in (0, 1):
+            raise ValueError("cfg_half is 0 (unconditional), 1 (conditional) or None")
+        if cfg_half is not None and cfg_exchange is None:
+            raise ValueError("cfg_half needs a cfg_exchange callable")
+        self.cfg_half, self.cfg_exchange = cfg_half, cfg_exchange
+        self._eps_half = None
 
     # ---------------------------------------------------------------------------- inputs ----
     def set_inputs(self, latents, prompt_embeds, camera_param, bboxes_list, conds):
@@ -79,6 +88,16 @@ class BEVDenoiser:
         self.m = 2 * b * n
         flat = latents.reshape(b * n, c, h, w).to(dt)
         self.lat2 = torch.stack([flat, flat]).contiguous()              # (2, b*n, 4, h, w): CFG duplicate
+        if self.cfg_half is not None:                                   # keep this rank's half of every input
+            hf = self.cfg_half
+            self.m = b * n
+
+            def half(x, per):
+                return x[hf * per:(hf + 1) * per]
+            prompt_embeds = half(prompt_embeds, b)
+            camera_param = half(camera_param, b)
+            bboxes_list = [None if d is None else {k: half(v, b) for k, v in d.items()} for d in bboxes_list]
+            conds = [half(cd, b if cd.shape[0] == 2 * b else b * n) for cd in conds]
         self.prompt_embeds = prompt_embeds.to(dt)
         self.camera_param = camera_param
         self.bboxes_list = bboxes_list
@@ -105,7 +124,8 @@ class BEVDenoiser:
     # ------------------------------------------------------------------------------ step ----
     def _step_body(self):
         m, h, w = self.m, self.h, self.w
-        x8 = O.nchw_to_nhwc(self.lat2.reshape(m, 4, h, w), 8)           # latent_model_input, NHWC pad 8
+        lat_in = self.lat2[0] if self.cfg_half is not None else self.lat2.reshape(m, 4, h, w)
+        x8 = O.nchw_to_nhwc(lat_in, 8)                                  # latent_model_input, NHWC pad 8
         n = len(self.controlnets)
         if not self.parallel_branches:
             prep = self._prepared if self._prepared is not None else self._prepare()
@@ -157,9 +177,19 @@ class BEVDenoiser:
                 down = [tuple(results[i][j][0] for i in range(n)) for j in range(len(results[0]) - 1)]
                 mid = tuple(results[i][-1][0] for i in range(n))
             eps = self.unet.decode_nhwc(state, down, mid)
+        if self.cfg_half is not None:                                   # combine happens after the exchange
+            self._eps_half = eps
+            return eps
         O.cfg_ddim_step(eps, self.lat2[0], self.coef, self.guidance_scale,
                         x_out=self.lat2[0], x_dup=self.lat2[1])          # :487-499
         return eps
+
+    def _combine_halves(self):
+        """CFG split: exchange the two halves' noise predictions, then guidance + DDIM on both ranks
+        (each keeps the full latents; the update is deterministic and identical)."""
+        eps2 = self.cfg_exchange(self._eps_half)
+        O.cfg_ddim_step(eps2, self.lat2[0], self.coef, self.guidance_scale,
+                        x_out=self.lat2[0], x_dup=self.lat2[1])
 
     def capture(self):
         """Eager warm-up (packs weights, sizes workspaces) then records the step into a HIP graph."""
@@ -190,6 +220,8 @@ class BEVDenoiser:
             self._graph.replay()
         else:
             self._step_body()
+        if self.cfg_half is not None:
+            self._combine_halves()
 
     def run(self, steps: Optional[int] = None):
         for i in range(steps if steps is not None else self.num_inference_steps):

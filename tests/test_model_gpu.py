@@ -329,7 +329,39 @@ def test_full_step_dual_branch_graph_vs_oracle(unet_case, cnet_case, dtype):
                            [_to_dev(bx, dtype) for bx in boxes], [_to_dev(c, dtype) for c in conds])
             den.run(2)
         outs[(graph, hoist)] = den.latents.float().cpu()
+    # ---- CFG split: the two halves as separate 6-instance denoisers exchanging their
+    # noise predictions every step (here through a local stand-in for parallel.cfg_all_gather)
+    box = {}
+
+    def make_exchange(hf):
+        def exchange(eps_half):
+            box[hf] = eps_half
+            if len(box) < 2:
+                return None
+            return torch.stack([box[0], box[1]])
+        return exchange
+
+    halves = []
+    for hf in (0, 1):
+        d = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50, use_graph=True,
+                        cfg_half=hf, cfg_exchange=make_exchange(hf))
+        d._combine_halves = lambda: None            # the test drives the exchange itself (one process)
+        with torch.no_grad():
+            d.set_inputs(lat.cuda().to(dtype), _to_dev(prompt, dtype), _to_dev(cam, dtype),
+                         [_to_dev(bx, dtype) for bx in boxes], [_to_dev(c, dtype) for c in conds])
+        halves.append(d)
+    from dualdiff_amd import ops as O
+    with torch.no_grad():
+        for i in range(2):
+            for d in halves:
+                d.step(i)
+            eps2 = torch.stack([halves[0]._eps_half, halves[1]._eps_half])
+            for d in halves:
+                O.cfg_ddim_step(eps2, d.lat2[0], d.coef, d.guidance_scale, x_out=d.lat2[0], x_dup=d.lat2[1])
+    assert halves[0].m == 6 and torch.equal(halves[0].latents, halves[1].latents)
     rec = []
+    e3 = report("latents after 2 steps (CFG split)", halves[0].latents.float().cpu(), x, dtype, rec)
+    assert e3 <= 1.0, rec
     e = report("latents after 2 steps (graph)", outs[(True, False)], x, dtype, rec)
     e2 = report("latents after 2 steps (eager+hoist)", outs[(False, True)], x, dtype, rec)
     # graph replay and hoisting must not change results at all
