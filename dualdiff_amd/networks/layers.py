@@ -373,10 +373,11 @@ class Attention(_Cached):
         q = self.to_q.run(x2d) if norm is None else self.to_q.run_ln(x2d, norm)
         pre = self.__dict__.pop("_kv_prefetched", None)
         if kv is None and pre is not None and pre[0] is ctx2d:
-            kv, side = pre[1], pre[2]                # projected ahead of time on a side stream
-            torch.cuda.current_stream().wait_stream(side)
-            if not torch.cuda.is_current_stream_capturing():     # graph pools keep the block alive themselves
-                kv.record_stream(torch.cuda.current_stream())
+            kv, side = pre[1], pre[2]                # projected ahead of time (bank GEMM, or a side stream)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                if not torch.cuda.is_current_stream_capturing():     # graph pools keep the block alive themselves
+                    kv.record_stream(torch.cuda.current_stream())
         if kv is None:
             kv = self.project_kv(ctx2d)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale)
@@ -618,6 +619,43 @@ class TimeEmbProjBank:
             out[id(r)] = allv[:, off:off + r.out_channels]
             off += r.out_channels
         return out
+
+
+class CrossKVBank:
+    """K and V of EVERY text cross-attention (attn2) of a model for one context, as ONE GEMM per
+    forward: the context tokens are the same for all layers, so the [2C_l, 768] projection matrices
+    of the 16 (UNet) / 7 (ControlNet) layers are stacked along N and each layer attends to its column
+    slice of the result (the attention kernel takes row-strided K/V).  Replaces 16 / 7 small
+    launch-bound GEMMs on the serial chain by one 1176 x 24960 x 768 (UNet) GEMM."""
+
+    def __init__(self, model):
+        self.layers = []
+        for blk in model.modules():
+            mod = getattr(blk, "attn2", None) if isinstance(blk, BasicTransformerBlock) else None
+            if mod is not None and mod.is_cross:
+                self.layers.append(mod)
+        self._w = None
+        self._key = None
+
+    def run(self, ctx2d):
+        mods = [m for m in self.layers if isinstance(m.processor, HIPAttnProcessor)
+                and m.to_k.in_features == ctx2d.shape[1]]
+        if not mods:
+            return
+        key = tuple((m.to_k.weight._version, m.to_v.weight._version, m.to_k.weight.data_ptr()) for m in mods)
+        if self._w is None or self._key != key or self._w.dtype != ctx2d.dtype or self._w.device != ctx2d.device:
+            self._w = torch.cat([m._fused(("to_k", "to_v")) for m in mods], dim=0).contiguous()
+            self._key = key
+        allkv = O.gemm(ctx2d, self._w)
+        off = 0
+        for m in mods:
+            n2 = 2 * m.inner_dim
+            m.__dict__["_kv_prefetched"] = (ctx2d, allkv[:, off:off + n2], None)
+            off += n2
+
+    def drop(self):
+        for m in self.layers:
+            m.__dict__.pop("_kv_prefetched", None)
 
 
 def seeded_init_(module, seed=0):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import ops as O
 from .blocks import BasicMultiviewTransformerBlock
-from .layers import (prefetch_cross_kv, drop_prefetched_kv, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
+from .layers import (prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
                      TimestepEmbedding, Timesteps, UNetMidBlock2DCrossAttn, UpBlock2D, as_nchw_view,
                      run_down_block, run_up_block, to_nhwc)
 from .model_base import ModelBase
@@ -37,6 +37,8 @@ class UNet2DConditionModelMultiview(ModelBase):
     # (config 2, graph replay): 66.0 steps/s off vs 62.4 on — the extra stream's small GEMMs delay the
     # main chain more than they shorten it — so it is off; DD_PREFETCH_KV=1 turns it on.
     prefetch_kv = __import__('os').environ.get('DD_PREFETCH_KV', '0') == '1'
+    # all attn2 K/V projections of the model as one GEMM per forward (layers.CrossKVBank); DD_KV_BANK=0 disables
+    kv_bank = __import__('os').environ.get('DD_KV_BANK', '1') != '0'
 
     _WARN_ONCE = 0
 
@@ -233,7 +235,11 @@ class UNet2DConditionModelMultiview(ModelBase):
         """conv_in + down path + mid block — everything that does NOT depend on the ControlNet
         residuals, so a sampler can overlap it with the ControlNet branches on other streams."""
         dt = self.dtype
-        if self.prefetch_kv:
+        if self.kv_bank:
+            if self.__dict__.get("_kv_bank") is None:
+                self.__dict__["_kv_bank"] = CrossKVBank(self)
+            self.__dict__["_kv_bank"].run(ctx2d)
+        elif self.prefetch_kv:
             if self.__dict__.get("_kv_stream") is None:
                 self.__dict__["_kv_stream"] = torch.cuda.Stream()
             prefetch_cross_kv(self, ctx2d, self.__dict__["_kv_stream"])
@@ -282,4 +288,6 @@ class UNet2DConditionModelMultiview(ModelBase):
         a = self.conv_norm_out.run(x, m, h * w, True)
         if self.__dict__.get("_kv_stream") is not None:
             drop_prefetched_kv(self, self.__dict__["_kv_stream"])
+        if self.__dict__.get("_kv_bank") is not None:
+            self.__dict__["_kv_bank"].drop()
         return O.conv3x3_small_cout(a, self.conv_out.packed, self.conv_out.bias, m, h, w)

@@ -26,7 +26,7 @@ from .. import ops as O
 from ..misc.common import load_module
 from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor  # noqa: F401
 from .embedder import get_embedder
-from .layers import (prefetch_cross_kv, drop_prefetched_kv, Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
+from .layers import (prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
                      UNetMidBlock2DCrossAttn, as_nchw_view, run_down_block, to_nhwc)
 from .model_base import ModelBase
 from .output_cls import BEVControlNetOutput
@@ -57,6 +57,8 @@ class BEVControlNetModel(ModelBase):
     # forked stream forks again (tools/capture_topology.py reproduces it); only the UNet, which runs on
     # the capture's origin stream, prefetches.
     prefetch_kv = False
+    # all attn2 K/V projections of the branch as one GEMM per forward (layers.CrossKVBank)
+    kv_bank = __import__('os').environ.get('DD_KV_BANK', '1') != '0'
     _keys_to_ignore_on_load_missing = ("adm_proj", "txt_con_fusion", "txt_con_fusionp")
 
     def __init__(
@@ -323,7 +325,11 @@ class BEVControlNetModel(ModelBase):
         dt = self.dtype
         assert not self.use_cam_in_temb, "not available now (:954)"
         ctx2d, lc = prep.get("ctx2d_cn", prep["ctx2d"]), prep.get("lc_cn", prep["lc"])
-        if self.prefetch_kv:
+        if self.kv_bank:
+            if self.__dict__.get("_kv_bank") is None:
+                self.__dict__["_kv_bank"] = CrossKVBank(self)
+            self.__dict__["_kv_bank"].run(ctx2d)
+        elif self.prefetch_kv:
             if self.__dict__.get("_kv_stream") is None:
                 self.__dict__["_kv_stream"] = torch.cuda.Stream()
             prefetch_cross_kv(self, ctx2d, self.__dict__["_kv_stream"])
@@ -337,6 +343,8 @@ class BEVControlNetModel(ModelBase):
         x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc)
         if self.__dict__.get("_kv_stream") is not None:
             drop_prefetched_kv(self, self.__dict__["_kv_stream"])
+        if self.__dict__.get("_kv_bank") is not None:
+            self.__dict__["_kv_bank"].drop()
         outs = []
         for i, ((s, sh, sw), zc) in enumerate(zip(skips, self.controlnet_down_blocks)):       # :1031-1054
             dst = out[i][0] if out is not None else None
