@@ -161,8 +161,8 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
                 cands.append((t, tile, split))
     # the coarse pass is noisy: re-time the front-runners with more launches
     cands.sort()
-    for t, tile, split in cands[:5]:
-        t2 = timed(tile, split, 4 if _COLD else 12)
+    for t, tile, split in cands[:6]:
+        t2 = timed(tile, split, 6 if _COLD else 12)
         if t2 is not None and t2 < best_t:
             best, best_t = (tile, split), t2
     (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
