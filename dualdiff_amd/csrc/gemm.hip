@@ -18,6 +18,7 @@
 //    the same XCD (private L2).
 //  * split-K for the deep, weight-bound levels (336..1092 rows x K up to 23040).
 #include "dd_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -925,57 +926,87 @@ void dd_conv3s_kernel(const GemmParams p) {
       if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0);
   }
   int wslot = 0;                                        // ring slot of step s (scalar)
-  for (int c = 0; c < nc; ++c) {
-    const bool more_c = c + 1 < nc;
-    const T* ab = abuf + (c & 1) * AROWS * BK;
+  // Gathered activation fragments are double-buffered across steps: while the MFMAs of tap t run,
+  // the fragments of tap t+1 (same resident chunk; at t == 8 the next chunk, landed since step NSW-1)
+  // are already being read.  The buffer index is a compile-time parity, so the chunk loop is
+  // unrolled by two (9 taps per chunk is odd).
+  V8 xf[2][2][TM];
+  auto gather = [&](const T* ab, auto tap_c, auto par_c) __attribute__((always_inline)) {
+    constexpr int t = decltype(tap_c)::value;
+    constexpr int par = decltype(par_c)::value;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int s = c * 9 + t;
-      // W(s) (and with it, in issue order, A(c)) must have landed.  Younger loads that may stay in
-      // flight: W(s+1..s+NSW-2), and A(c+1) when it was issued after W(s) (1 <= t <= NSW-2).  The
-      // last NSW-2 steps simply drain.
-      if (s + NSW - 2 < nsteps) {
-        if (t >= 1 && t <= NSW - 2 && more_c) wait_vmcnt<(NSW - 2) * WI + XA>();
-        else wait_vmcnt<(NSW - 2) * WI>();
-      } else {
-        wait_vmcnt<0>();
-      }
-      __builtin_amdgcn_s_barrier();
-      if (t == 0 && more_c) issue_a(c + 1);
-      if (s + NSW - 1 < nsteps) {
-        int slot = wslot + NSW - 1;
-        if (slot >= NSW) slot -= NSW;
-        const int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;     // constants after unrolling
-        issue_w(c + ca, ta, slot);
-      }
-      const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
-      if (++wslot == NSW) wslot = 0;
-      V8 wf[2][TN], xf[2][TM];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
-      }
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        uint32_t ra = (tab[j][t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-        asm volatile("" : "+v"(ra));     // keep the 54 gather addresses out of registers: recompute per step
-        const uint32_t c0 = (uint32_t)fchunk ^ ((ra >> 1) & 7u);
-        const T* src = ab + ra * BK;
-        xf[0][j] = dd_as_v8<T>(dd_ld16(src + (c0 << 3)));
-        xf[1][j] = dd_as_v8<T>(dd_ld16(src + ((c0 ^ 4u) << 3)));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
+    for (int j = 0; j < TM; ++j) {
+      uint32_t ra = (tab[j][t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+      asm volatile("" : "+v"(ra));       // keep the 54 gather addresses out of registers: recompute per step
+      const uint32_t c0 = (uint32_t)fchunk ^ ((ra >> 1) & 7u);
+      const T* src = ab + ra * BK;
+      xf[par][0][j] = dd_as_v8<T>(dd_ld16(src + (c0 << 3)));
+      xf[par][1][j] = dd_as_v8<T>(dd_ld16(src + ((c0 ^ 4u) << 3)));
     }
+  };
+  auto step = [&](const int c, auto tap_c, auto par_c) __attribute__((always_inline)) {
+    constexpr int t = decltype(tap_c)::value;
+    constexpr int par = decltype(par_c)::value;
+    const bool more_c = c + 1 < nc;
+    const int s = c * 9 + t;
+    // W(s) (and with it, in issue order, A(c)) must have landed.  Younger loads that may stay in
+    // flight: W(s+1..s+NSW-2), and A(c+1) when it was issued after W(s) (1 <= t <= NSW-2).  The
+    // last NSW-2 steps simply drain.
+    if (s + NSW - 2 < nsteps) {
+      if (t >= 1 && t <= NSW - 2 && more_c) wait_vmcnt<(NSW - 2) * WI + XA>();
+      else wait_vmcnt<(NSW - 2) * WI>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t == 0 && more_c) issue_a(c + 1);
+    if (s + NSW - 1 < nsteps) {
+      int slot = wslot + NSW - 1;
+      if (slot >= NSW) slot -= NSW;
+      constexpr int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;
+      issue_w(c + ca, ta, slot);
+    }
+    const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
+    if (++wslot == NSW) wslot = 0;
+    V8 wf[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+    }
+    if (s == 0) gather(abuf, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // first step only
+    // next step's activation fragments (other parity)
+    if (t < 8) {
+      gather(abuf + (c & 1) * AROWS * BK, std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, par ^ 1>{});
+    } else if (more_c) {
+      gather(abuf + ((c + 1) & 1) * AROWS * BK, std::integral_constant<int, 0>{}, std::integral_constant<int, par ^ 1>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[par][ks][j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto chunk = [&](const int c, auto par0) __attribute__((always_inline)) {
+    constexpr int p0 = decltype(par0)::value;
+    step(c, std::integral_constant<int, 0>{}, std::integral_constant<int, p0>{});
+    step(c, std::integral_constant<int, 1>{}, std::integral_constant<int, p0 ^ 1>{});
+    step(c, std::integral_constant<int, 2>{}, std::integral_constant<int, p0>{});
+    step(c, std::integral_constant<int, 3>{}, std::integral_constant<int, p0 ^ 1>{});
+    step(c, std::integral_constant<int, 4>{}, std::integral_constant<int, p0>{});
+    step(c, std::integral_constant<int, 5>{}, std::integral_constant<int, p0 ^ 1>{});
+    step(c, std::integral_constant<int, 6>{}, std::integral_constant<int, p0>{});
+    step(c, std::integral_constant<int, 7>{}, std::integral_constant<int, p0 ^ 1>{});
+    step(c, std::integral_constant<int, 8>{}, std::integral_constant<int, p0>{});
+  };
+  for (int c = 0; c < nc; c += 2) {
+    chunk(c, std::integral_constant<int, 0>{});            // even chunk: tap t uses parity t & 1
+    if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{});   // odd chunk: parity (t + 1) & 1
   }
   // rows past the tile's instances are padding
   store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows),
