@@ -81,6 +81,43 @@ void dd_timestep_embedding_kernel(const float* t, T* out, int n, int dim, int fl
   }
 }
 
+// ORS ray sampling: one thread per (camera, sample, pixel), pixel fastest (coalesced condition
+// writes).  fp32 with the reference's operation order and NO fma contraction: the result is a voxel
+// index, a last-bit difference could flip a class.
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_ors_project_kernel(const uint8_t* __restrict__ occ, const float* __restrict__ origin,
+                           const float* __restrict__ dir, uint8_t* __restrict__ labels, T* __restrict__ cond,
+                           int n_cam, int hw, int samples, float step, int keep_fg, int keep_bg) {
+  const int64_t total = (int64_t)n_cam * samples * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pix = (int)(i % hw);
+    const int64_t r = i / hw;
+    const int s = (int)(r % samples);
+    const int cam = (int)(r / samples);
+    const float t = __fmul_rn((float)s, step);
+    const float* o = origin + cam * 3;
+    const float* d = dir + ((int64_t)cam * hw + pix) * 3;
+    float g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g[a] = __fdiv_rn(__fadd_rn(o[a], __fmul_rn(t, d[a])), 40.0f);
+    const float gz = __fsub_rn(__fdiv_rn(__fmul_rn(g[2], 40.0f), 3.2f), 0.6875f);
+    auto idx = [](float c, float size) -> int {       // grid_sample nearest, align_corners = False
+      return (int)rintf(__fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(c, 1.0f), size), 1.0f), 2.0f));
+    };
+    const int ix = idx(g[0], 200.0f), iy = idx(g[1], 200.0f), iz = idx(gz, 16.0f);
+    int lab = 17;
+    if (ix >= 0 && ix < 200 && iy >= 0 && iy < 200 && iz >= 0 && iz < 16) lab = occ[(ix * 200 + iy) * 16 + iz];
+    if (labels) labels[((int64_t)cam * hw + pix) * samples + s] = (uint8_t)lab;
+    if (cond) {
+      int c = lab;
+      if (!keep_fg && c <= 10) c = 17;
+      if (!keep_bg && c >= 11) c = 17;
+      cond[i] = (T)__fdiv_rn((float)c, 17.0f);
+    }
+  }
+}
+
 struct FourierFreqs { float f[16]; };
 
 template <typename TI, typename TO>
@@ -270,6 +307,24 @@ extern "C" int dd_timestep_embedding(const float* t, void* out, int32_t n, int32
   else
     hipLaunchKernelGGL(dd_timestep_embedding_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, s,
                        t, (__bf16*)out, n, dim, flip_sin_to_cos, freq_shift);
+  return dd_check_launch();
+}
+
+extern "C" int dd_ors_project(const uint8_t* occ, const float* origin, const float* dir, uint8_t* labels,
+                              void* cond, int32_t n_cam, int32_t hw, int32_t samples, float step,
+                              int32_t keep_fg, int32_t keep_bg, int32_t dtype, dd_stream_t stream) {
+  if (!occ || !origin || !dir || (!labels && !cond) || n_cam <= 0 || hw <= 0 || samples <= 0) return DD_ERR_BAD_ARG;
+  if (cond && dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
+  const int64_t total = (int64_t)n_cam * samples * hw;
+  const unsigned g = (unsigned)grid_for(total > (1 << 30) ? (1 << 30) : (int)total);
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_ors_project_kernel<_Float16>, dim3(g), dim3(256), 0, s, occ, origin, dir, labels,
+                       (_Float16*)cond, n_cam, hw, samples, step, keep_fg, keep_bg);
+  else
+    hipLaunchKernelGGL(dd_ors_project_kernel<__bf16>, dim3(g), dim3(256), 0, s, occ, origin, dir, labels,
+                       (__bf16*)cond, n_cam, hw, samples, step, keep_fg, keep_bg);
   return dd_check_launch();
 }
 

@@ -512,6 +512,29 @@ def cfg_ddim_step(eps, x, coef, guidance, x_out=None, x_dup=None):
     return x_out
 
 
+def ors_project(occ, origin, direction, samples, step=0.2, *, want_labels=True, cond_dtype=None,
+                keep_fg=True, keep_bg=True):
+    """ORS ray sampling (include/dualdiff_hip.h: dd_ors_project).  occ: (200, 200, 16) uint8 on the GPU;
+    origin (n, 3), direction (n, hw, 3) fp32.  Returns (labels (n, hw, samples) uint8 | None,
+    cond (n, samples, hw) cond_dtype | None)."""
+    lib = _native.load()
+    _need_gpu(occ, origin, direction)
+    if occ.dtype != torch.uint8 or tuple(occ.shape) != (200, 200, 16) or not occ.is_contiguous():
+        raise ValueError("occ must be a contiguous (200, 200, 16) uint8 volume")
+    origin = origin.to(torch.float32).contiguous()
+    direction = direction.to(torch.float32).contiguous()
+    n, hw = direction.shape[0], direction.shape[1]
+    labels = torch.empty((n, hw, samples), dtype=torch.uint8, device=occ.device) if want_labels else None
+    cond = torch.empty((n, samples, hw), dtype=cond_dtype, device=occ.device) if cond_dtype is not None else None
+    code = DD_F16 if cond_dtype in (None, torch.float16) else DD_BF16
+    if cond_dtype not in (None, torch.float16, torch.bfloat16):
+        raise TypeError("cond_dtype must be fp16 / bf16")
+    _native.check(lib.dd_ors_project(_ptr(occ), _ptr(origin), _ptr(direction), _ptr(labels), _ptr(cond), n, hw,
+                                     int(samples), float(step), int(keep_fg), int(keep_bg), code, _stream()),
+                  "ors_project")
+    return labels, cond
+
+
 def fourier_embed(x, freqs, include_input=True):
     """[x, sin(f0 x), cos(f0 x), ...] on the last dim (networks/embedder.py), one kernel."""
     lib = _native.load()

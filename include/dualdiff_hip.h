@@ -215,6 +215,21 @@ int dd_fourier_embed(const void* x, void* out, int64_t rows, int32_t dims, const
                      int32_t num_freqs, int32_t include_input, int32_t in_dtype, int32_t out_dtype,
                      dd_stream_t stream);
 
+/* ORS projection (networks/occ3d_proj.py:49-113 + dataset/utils.py:412-420): every
+ * latent pixel's ray is sampled at `samples` equidistant points (step metres apart) in a
+ * 200 x 200 x 16 class volume (uint8, x-major, 0.4 m voxels: x, y in [-40, 40) m, z in [-1, 5.4) m);
+ * the nearest voxel's class is taken, 17 outside the volume.
+ *   origin [n_cam][3], dir [n_cam][hw][3]: fp32 ray origins / unit directions (ego frame);
+ *   labels (may be NULL): uint8 [n_cam][hw][samples];
+ *   cond   (may be NULL): [n_cam][samples][hw] in `dtype` = class / 17 after the optional
+ *           foreground (class <= 10 -> 17, keep_fg == 0) / background (class >= 11 -> 17, keep_bg == 0)
+ *           filtering — the ORS-3D ControlNet condition (unet_addon_rawbox.py:967-990).
+ * Integer output: bit-exact against the reference's fp32 arithmetic (separate multiply / add, true
+ * divisions, round-half-even). */
+int dd_ors_project(const uint8_t* occ, const float* origin, const float* dir, uint8_t* labels, void* cond,
+                   int32_t n_cam, int32_t hw, int32_t samples, float step, int32_t keep_fg, int32_t keep_bg,
+                   int32_t dtype, dd_stream_t stream);
+
 /* conv3x3 with tiny Cout (conv_out 320->4): y NCHW fp32/T. x NHWC (rows, cin),
  * w [cout][9*cin]; writes y as NCHW (m, cout, h, w) in dtype T.
  * (networks/unet_2d_condition_multiview.py:522) */

@@ -152,3 +152,40 @@ def compare(npz, key, t, rtol, atol):
     assert abs(s - float(npz[key + "__sum"])) <= tol, (key, "sum", s, float(npz[key + "__sum"]))
     assert abs(a - float(npz[key + "__abssum"])) <= tol, (key, "abssum")
     return err
+
+
+# ------------------------------------------------------------------- ORS projection (N3) ----
+ORS_H, ORS_W, ORS_S = 28, 50, 320
+ORS_RATIO = 400 / 8 / 1600            # misc/test_utils.py:215 for 224x400 images
+ORS_VIEWS = ["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_RIGHT", "CAM_BACK", "CAM_BACK_LEFT"]
+
+
+def ors_inputs():
+    """Seeded stand-ins for the reference's data files: a 200 x 200 x 16 class volume (0..17) with
+    structure (ground plane, boxes), and 6 cameras on a ring looking outwards (nuScenes-like
+    intrinsics for a 1600 x 900 image, camera ~1.5 m above the ground)."""
+    import math
+    g = torch.Generator().manual_seed(131)
+    occ = torch.full((200, 200, 16), 17, dtype=torch.int64)
+    occ[:, :, 2] = 11                                           # drivable surface layer
+    occ[:, :, :2] = 15
+    for _ in range(60):                                         # boxes of random classes
+        x0, y0 = int(torch.randint(0, 190, (1,), generator=g)), int(torch.randint(0, 190, (1,), generator=g))
+        sx, sy, sz = [int(torch.randint(2, 10, (1,), generator=g)) for _ in range(3)]
+        occ[x0:x0 + sx, y0:y0 + sy, 3:3 + sz] = int(torch.randint(0, 17, (1,), generator=g))
+    Ks, Rts = [], []
+    for i in range(6):
+        yaw = math.radians(55.0 - 60.0 * i) + float(torch.rand(1, generator=g) - 0.5) * 0.1
+        # camera axes in the ego frame: z forward (along yaw), x right, y down
+        fwd = torch.tensor([math.cos(yaw), math.sin(yaw), 0.0])
+        down = torch.tensor([0.0, 0.0, -1.0])
+        right = torch.linalg.cross(down, fwd)
+        R = torch.stack([right, down, fwd], dim=1)               # columns = camera axes
+        t = torch.tensor([1.5 * math.cos(yaw), 0.5 * math.sin(yaw), 1.5])
+        Rt = torch.eye(4)
+        Rt[:3, :3], Rt[:3, 3] = R, t
+        f = 1260.0 + 10.0 * i
+        K = torch.tensor([[f, 0.0, 800.0 + i], [0.0, f, 450.0 - i], [0.0, 0.0, 1.0]])
+        Ks.append(K)
+        Rts.append(Rt)
+    return occ, Ks, Rts

@@ -13,7 +13,8 @@ copied):
 
 Consequences for pinning (DESIGN.md "Oracle"):
   LEVEL 1 (true reference arithmetic; only the SDPA stand-in is ours):
-      sfa, sfa_plus, cond_embedder, bbox_embedder, attn_processor, adapter_processor
+      sfa, sfa_plus, cond_embedder, bbox_embedder, attn_processor, adapter_processor,
+      ors_projection (integer labels, bit-exact)
   LEVEL 2 (reference control flow executed verbatim over our restated leaf modules):
       multiview_block, unet_multiview, controlnet_bg, controlnet_fg, controlnet_bg_adapter
 
@@ -212,6 +213,42 @@ def main():
             save(name + "_adapter", mid=mid, ctx=ctx, **arrays)
 
 
+def mint_ors():
+    """LEVEL 1: the reference's own `OccupancyRay.project` (networks/occ3d_proj.py:49-113) on seeded
+    stand-ins for its data files.  `cv2` is a name-only stub; the stub `Quaternion` returns the rotation
+    MATRIX stored in the fake camera table, so no quaternion arithmetic of ours enters."""
+    import tempfile
+    _mod("cv2")
+
+    class Quaternion:
+        def __init__(self, rot):
+            self.rotation_matrix = np.asarray(rot, dtype=np.float64)
+    _mod("pyquaternion", Quaternion=Quaternion)
+    from magicdrive.networks import occ3d_proj as ref_ors
+    occ, Ks, Rts = C.ors_inputs()
+    tok = "seeded-sample"
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, "scene"))
+        np.savez(os.path.join(root, "scene", "labels.npz"), semantics=occ.numpy().astype(np.uint8))
+        proj = object.__new__(ref_ors.OccupancyRay)               # skip __init__: it unpickles data files
+        proj.camera_data = {tok: {v: {"translation": Rts[i][:3, 3].tolist(), "rotation": Rts[i][:3, :3].numpy(),
+                                      "intrinsic": Ks[i].tolist()} for i, v in enumerate(C.ORS_VIEWS)}}
+        proj.occ3d_idx = {tok: "scene"}
+        proj.device = "cpu"
+        proj.dataroot = root
+        proj.image_shape = (896, 1600)
+        proj.sample_point = C.ORS_S
+        proj.sample_step = 0.2
+        proj.compress_ratio = C.ORS_RATIO
+        proj.image_shape_compress = [int(896 * C.ORS_RATIO), int(1600 * C.ORS_RATIO)]
+        labels = proj.project(tok)                                 # (6, 28, 50, 320) int64
+    assert tuple(labels.shape) == (6, C.ORS_H, C.ORS_W, C.ORS_S), labels.shape
+    path = os.path.join(HERE, "ors_projection.npz")
+    np.savez_compressed(path, labels=labels.numpy().astype(np.uint8))
+    print("wrote %s (%.1f KB); classes seen: %s" % (path, os.path.getsize(path) / 1024,
+                                                      sorted(set(labels.unique().tolist()))))
+
+
 def _self_attn():
     a = D.Attention(query_dim=320, heads=8, dim_head=40)
     a.load_state_dict(seeded_state_dict(a, C.SEED_PROC + 1))
@@ -219,4 +256,9 @@ def _self_attn():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ors":
+        install_stubs()
+        mint_ors()
+    else:
+        main()
+        mint_ors()

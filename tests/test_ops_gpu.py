@@ -442,3 +442,72 @@ def test_cfg_ddim(ops, dtype):
 def test_fails_loudly_on_cpu_tensor(ops):
     with pytest.raises(RuntimeError):
         ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))
+
+
+# ------------------------------------------------------------------ ORS projection (N3) ----
+@torch.no_grad()
+def test_ors_projection_bit_exact_gpu():
+    """dd_ors_project through dualdiff_amd.networks.occ3d_proj.OccupancyRay against (a) the labels the
+    reference's own project() produced (golden) and (b) the oracle — integer work, every label equal."""
+    import os
+    import numpy as np
+    from oracle import ors_projection as P
+    from tests.golden import cases as C
+    from dualdiff_amd.networks.occ3d_proj import OccupancyRay
+    occ, Ks, Rts = C.ors_inputs()
+    proj = OccupancyRay(image_shape=(900, 1600), sample_point=C.ORS_S, sample_step=0.2,
+                        compress_ratio=C.ORS_RATIO, device="cuda")
+    assert proj.image_shape_compress == [C.ORS_H, C.ORS_W]
+    lab = proj.project_volume(occ, Ks, Rts).cpu()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ors_projection.npz"))["labels"]
+    ref = torch.from_numpy(gold.astype(np.int64))
+    assert lab.shape == ref.shape
+    assert torch.equal(lab, ref), "%d of %d labels differ from the reference" % ((lab != ref).sum().item(), ref.numel())
+    assert torch.equal(lab, P.ors_project(occ, Ks, Rts, C.ORS_H, C.ORS_W, C.ORS_RATIO, C.ORS_S, 0.2))
+    # fused condition output: filtering + /17 + channels-first, in the branch's storage dtype
+    for fg, bg in ((True, True), (True, False), (False, True)):
+        for dt in (torch.float16, torch.bfloat16):
+            cond = proj.condition_volume(occ, Ks, Rts, dtype=dt, use_fg=fg, use_bg=bg).cpu()
+            want = P.ors_condition(ref, use_fg=fg, use_bg=bg).to(dt)
+            assert torch.equal(cond, want), (fg, bg, dt)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_ors_projection_random_rigs(seed):
+    """Random volumes and rigs (cameras inside and outside the volume, rays leaving through every face,
+    other latent sizes / sample counts): bit-exact against the oracle."""
+    from oracle import ors_projection as P
+    from dualdiff_amd.networks.occ3d_proj import OccupancyRay
+    g = torch.Generator().manual_seed(900 + seed)
+    occ = torch.randint(0, 18, (200, 200, 16), generator=g)
+    h, w, s = [(7, 13, 64), (28, 50, 200), (16, 9, 511)][seed]
+    Ks, Rts = [], []
+    for i in range(3 + seed):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+        Rt = torch.eye(4, dtype=torch.float64)
+        Rt[:3, :3] = q
+        Rt[:3, 3] = (torch.rand(3, generator=g, dtype=torch.float64) - 0.5) * torch.tensor([90.0, 90.0, 8.0])
+        Rt[2, 3] += 2.0
+        K = torch.tensor([[1260.0 + 10 * i, 0.0, 800.0], [0.0, 1255.0, 450.0 + 5 * i], [0.0, 0.0, 1.0]])
+        Ks.append(K)
+        Rts.append(Rt.float())
+    ratio = w / 1600
+    proj = OccupancyRay(image_shape=(h / ratio + 0.5, 1600), sample_point=s, sample_step=0.25 if seed == 2 else 0.2,
+                        compress_ratio=ratio, device="cuda")
+    assert proj.image_shape_compress == [h, w]
+    lab = proj.project_volume(occ, Ks, Rts).cpu()
+    want = P.ors_project(occ, Ks, Rts, h, w, ratio, s, proj.sample_step)
+    assert torch.equal(lab, want), "%d of %d labels differ" % ((lab != want).sum().item(), want.numel())
+    assert (lab == 17).any() and (lab != 17).any()
+
+
+def test_ors_projection_rejects_bad_input():
+    from dualdiff_amd import ops as O
+    occ = torch.zeros((200, 200, 8), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        O.ors_project(occ, torch.zeros(1, 3, device="cuda"), torch.zeros(1, 4, 3, device="cuda"), 8)
+    occ = torch.zeros((200, 200, 16), dtype=torch.uint8, device="cuda")
+    with pytest.raises(TypeError):
+        O.ors_project(occ, torch.zeros(1, 3, device="cuda"), torch.zeros(1, 4, 3, device="cuda"), 8,
+                      cond_dtype=torch.float32)

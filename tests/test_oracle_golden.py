@@ -151,3 +151,20 @@ def test_state_dict_contract_sd15():
     assert csd["bbox_embedder.bbox_proj.weight"].shape == (768, 216)
     assert csd["txt_con_fusion.to_k.weight"].shape == (320, 768)
     assert csd["controlnet_cond_embedding.blocks.5.weight"].shape == (256, 96, 3, 3)
+
+
+@torch.no_grad()
+def test_ors_projection_bit_exact():
+    """N3: the ORS ray-sampling restatement against the reference's own OccupancyRay.project on the
+    seeded volume and cameras — integer labels, every one of the 6 x 28 x 50 x 320 samples equal."""
+    from oracle import ors_projection as P
+    occ, Ks, Rts = C.ors_inputs()
+    lab = P.ors_project(occ, Ks, Rts, C.ORS_H, C.ORS_W, C.ORS_RATIO, C.ORS_S, 0.2)
+    ref = torch.from_numpy(gold("ors_projection")["labels"].astype(np.int64))
+    assert lab.shape == ref.shape == (6, C.ORS_H, C.ORS_W, C.ORS_S)
+    assert torch.equal(lab, ref), "%d of %d labels differ" % ((lab != ref).sum().item(), ref.numel())
+    # the volume is actually hit: a fair share of samples is not "free / outside"
+    assert 0.02 < (ref != 17).float().mean().item() < 0.9
+    cond = P.ors_condition(lab, use_fg=True, use_bg=False)
+    assert cond.shape == (6, C.ORS_S, C.ORS_H, C.ORS_W) and cond.max().item() <= 1.0
+    assert not ((cond * 17).round() >= 11).logical_and((cond * 17).round() < 17).any()     # backgrounds filtered
