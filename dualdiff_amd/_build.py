@@ -55,7 +55,7 @@ def build_native(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-             "-DNDEBUG"]
+             "-DNDEBUG"] + os.environ.get("DD_HIP_DEFINES", "").split()
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))

@@ -289,6 +289,287 @@ void dd_attn_kernel(const AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v5: same products and register layout as dd_attn_kernel, with the per-tile overhead taken out of
+// the instruction stream (the d = 40 loop is VALU-issue-bound: ~45 % of its slots were bookkeeping):
+//  * K/V rows come in through buffer loads with the hardware range check — per-lane byte offsets
+//    are computed once, rows past lk read as zeros, no compare / branch per load;
+//  * the zero padding of K (d..DQ) and the ones column of V live in LDS columns that the tile
+//    stores never touch: written once, not per tile;
+//  * head dims with a spare PV column (d = 40): keys past lk need NO score mask — their V row and
+//    their ones-column entry are zero, so whatever probability they get contributes nothing to the
+//    numerator or the denominator.  Only the running max must not see them, and that is handled
+//    inside the (rare) rescale branch; the common path has no tail code at all;
+//  * NBUF = 2: two LDS tiles, one barrier per tile instead of two.
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE>
+__global__ __launch_bounds__(256, WPE)
+void dd_attn5_kernel(const AttnParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  using V4 = typename dd_vec<T>::v4;
+  constexpr int DQ = (D + 31) / 32 * 32;
+  constexpr int KSTEPS = DQ / 32;
+  constexpr int DVT = (D + 15) / 16;
+  constexpr int KSTR = DQ + 16;
+  constexpr int VSTR = DVT * 16 + (D == 160 ? 16 : 0);
+  constexpr int KCH = DQ / 8;
+  constexpr int VCH = DVT * 2;
+  constexpr int DCH = D / 8;
+  constexpr bool ONES = (D % 16) != 0;
+  constexpr int NCH = KV_TILE * DCH;                 // valid 16-B chunks per K (and per V) tile
+  constexpr int PER = (NCH + 255) / 256;
+  constexpr bool RAGGED = (NCH % 256) != 0;          // last per-thread slot only partly populated
+  constexpr int TILE_ELEMS = KV_TILE * (KSTR + VSTR);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lds = reinterpret_cast<T*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int g = lane >> 4;
+  const int c = lane & 15;
+
+  const int nqb = p.nqb;
+  const int nwg = nqb * p.batch * p.heads;
+  const int xcd = blockIdx.x & 7;
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int item = ((xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int bh = item / nqb;
+  const int qb = item - bh * nqb;
+  const int b = bh / p.heads;
+  const int h = bh - b * p.heads;
+  const int kb = p.kv_map ? p.kv_map[b] : b;
+  const int q0 = (qb * 4 + wave) * (QT * 16);
+
+  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * D;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * D;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * D;
+  const uint32_t k_row_bytes = (uint32_t)p.ldk * sizeof(T), v_row_bytes = (uint32_t)p.ldv * sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(kbase), 0, (uint32_t)(p.lk - 1) * k_row_bytes + D * sizeof(T), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(vbase), 0, (uint32_t)(p.lk - 1) * v_row_bytes + D * sizeof(T), 0x00020000);
+
+  // per-lane chunk tables: global byte offsets inside a tile and LDS element offsets
+  uint32_t gk[PER], gv[PER];
+  int lk_off[PER], lv_off[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / DCH, ch = idx - row * DCH;
+    gk[i] = (uint32_t)row * k_row_bytes + ch * 16;
+    gv[i] = (uint32_t)row * v_row_bytes + ch * 16;
+    lk_off[i] = row * KSTR + ch * 8;
+    lv_off[i] = KV_TILE * KSTR + row * VSTR + ch * 8;
+  }
+  const bool last_slot = !RAGGED || (tid + (PER - 1) * 256 < NCH);
+
+  // ---- one-time LDS columns: K zero padding, V ones column ----------------------------------
+  {
+    const T one_t = (T)1.0f;
+    unsigned short one_u16;
+    __builtin_memcpy(&one_u16, &one_t, 2);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const u32x4 ones = {(unsigned)one_u16, 0u, 0u, 0u};
+    for (int idx = tid; idx < NBUF * KV_TILE; idx += 256) {
+      const int buf = idx / KV_TILE, row = idx - buf * KV_TILE;
+      T* kr = lds + buf * TILE_ELEMS + row * KSTR;
+#pragma unroll
+      for (int ch = DCH; ch < KCH; ++ch) dd_st16(kr + ch * 8, zero);
+      if (ONES) dd_st16(lds + buf * TILE_ELEMS + KV_TILE * KSTR + row * VSTR + DCH * 8, ones);
+    }
+  }
+
+  V8 qf[QT][KSTEPS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + c;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < p.lq && d0 < D) v = dd_ld16(qbase + (int64_t)qrow * p.ldq + d0);
+      qf[qt][ks] = dd_as_v8<T>(v);
+    }
+  }
+
+  f32x4 oacc[DVT][QT];
+#pragma unroll
+  for (int i = 0; i < DVT; ++i)
+#pragma unroll
+    for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) { m_run[j] = -1e30f; l_run[j] = 0.f; }
+
+  u32x4 kreg[PER], vreg[PER];
+  auto load_kv = [&](int tile0) {
+    const uint32_t ko = (uint32_t)tile0 * k_row_bytes, vo = (uint32_t)tile0 * v_row_bytes;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, gk[i] + ko, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, gv[i] + vo, 0, 0);
+  };
+  auto store_kv = [&](T* tile) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (i < PER - 1 || last_slot) {
+        dd_st16(tile + lk_off[i], kreg[i]);
+        dd_st16(tile + lv_off[i], vreg[i]);
+      }
+  };
+
+  const int ntiles = (p.lk + KV_TILE - 1) / KV_TILE;
+  load_kv(0);
+
+  for (int it = 0; it < ntiles; ++it) {
+    const int tile0 = it * KV_TILE;
+    T* tile = lds + (NBUF == 2 ? (it & 1) * TILE_ELEMS : 0);
+    const T* Ks = tile;
+    const T* Vs = tile + KV_TILE * KSTR;
+    if (NBUF == 1) __syncthreads();       // previous tile fully consumed by every wave
+    store_kv(tile);
+    if (ONES && tile0 + KV_TILE > p.lk) { // last, ragged tile: rows past lk lose their ones entry
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      if (tid < KV_TILE && tile0 + tid >= p.lk) dd_st16(tile + KV_TILE * KSTR + tid * VSTR + DCH * 8, zero);
+    }
+    __syncthreads();                      // tile visible (NBUF == 2: and the other buffer is free)
+    if (it + 1 < ntiles) load_kv(tile0 + KV_TILE);
+
+#pragma unroll
+    for (int cc = 0; cc < KV_TILE / 32; ++cc) {
+      const int key0 = tile0 + cc * 32;
+      if (key0 >= p.lk) break;
+      f32x4 sacc[2][QT];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        V8 kf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          kf[t] = dd_as_v8<T>(dd_ld16(Ks + (cc * 32 + t * 16 + c) * KSTR + ks * 32 + g * 8));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < QT; ++j)
+            sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[t][j]);
+      }
+      const bool tail = key0 + 32 > p.lk;             // uniform
+      V8 pf[QT];
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        float s[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t * 4 + r] = sacc[t][j][r];
+        auto mask_tail = [&]() {
+          int rem = p.lk - key0 - g * 4;       // pinned here: the compiler otherwise hoists the eight
+          asm volatile("" : "+v"(rem));        // compares of this rare path into the common block
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t * 16 + r >= rem) s[t * 4 + r] = -INFINITY;
+        };
+        if (!ONES && tail) mask_tail();
+        float mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
+                           fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {
+          if (ONES && tail) {          // the padded keys scored 0: keep them out of the running max
+            mask_tail();
+            mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
+                         fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+          }
+          float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+          m_run[j] = m_new;
+          if (!ONES) l_run[j] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DVT; ++dt) {
+            oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
+            oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
+          }
+        }
+        const float m_use = m_run[j];
+        float ls = 0.f;
+        V8 pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], p.scale_log2, -m_use));
+          if (!ONES) ls += pe;
+          pv[e] = (T)pe;
+        }
+        pf[j] = pv;
+        if (!ONES) l_run[j] += ls;
+      }
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt) {
+        V8 vf;
+        const T* a0 = Vs + (cc * 32 + g * 4 + (c >> 2)) * VSTR + dt * 16 + (c & 3) * 4;
+        const T* a1 = a0 + 16 * VSTR;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+        __builtin_memcpy(&vf, &lo, 8);
+        __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
+#pragma unroll
+        for (int j = 0; j < QT; ++j) oacc[dt][j] = dd_mfma16(vf, pf[j], oacc[dt][j]);
+      }
+    }
+  }
+
+  T* obase = reinterpret_cast<T*>(p.o) + (int64_t)b * p.obs + h * D;
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    float l;
+    if (ONES) {
+      l = __shfl(oacc[DVT - 1][j][D % 4], ((D % 16) / 4) * 16 + c, 64);
+    } else {
+      l = l_run[j];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    const int qrow = q0 + j * 16 + c;
+    if (qrow >= p.lq) continue;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      const int d0 = dt * 16 + g * 4;
+      if (d0 >= D) continue;
+      T* dst = obase + (int64_t)qrow * p.ldo + d0;
+      float o4[4] = {oacc[dt][j][0] * inv, oacc[dt][j][1] * inv, oacc[dt][j][2] * inv, oacc[dt][j][3] * inv};
+      if (p.accumulate) {
+        V4 prev = *reinterpret_cast<const V4*>(dst);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] += (float)prev[e];
+      }
+      V4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (T)o4[e];
+      *reinterpret_cast<V4*>(dst) = ov;
+    }
+  }
+}
+
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE = 1>
+int launch_attn5(const AttnParams& p, hipStream_t s) {
+  constexpr int DQ = (D + 31) / 32 * 32;
+  constexpr int DVT = (D + 15) / 16;
+  constexpr size_t smem = (size_t)NBUF * KV_TILE * ((DQ + 16) + (DVT * 16 + (D == 160 ? 16 : 0))) * sizeof(T);
+  const int qblk = 4 * QT * 16;
+  AttnParams pp = p;
+  pp.nqb = (p.lq + qblk - 1) / qblk;
+  dim3 grid(pp.nqb * p.batch * p.heads);
+  auto kern = dd_attn5_kernel<T, D, QT, KV_TILE, NBUF, WPE>;
+  if (smem > 65536) {
+    static bool once = false;       // per instantiation
+    if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, pp);
+  return dd_check_launch();
+}
+
 template <typename T, int D, int QT, bool TR, int KV_TILE>
 int launch_attn(const AttnParams& p, hipStream_t s) {
   constexpr int DQ = (D + 31) / 32 * 32;
@@ -315,8 +596,48 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
   if (variant == 2) { if constexpr (D <= 80) return launch_attn<T, D, 1, true, 128>(p, s); }
   if (variant == 3) return launch_attn<T, D, 2, true, 64>(p, s);
   if (variant == 4) return launch_attn<T, D, 1, true, 64>(p, s);
-  // (d = 40 with 16 rows per wave x 64-key tiles is 5-7 % faster back-to-back, tools/attn_variants.py,
-  //  but neutral inside the step; the default stays 32 rows x 128 keys)
+  if (variant == 13) {        // the round-1 default before the v5 family
+    if constexpr (D <= 80) {
+      if (p.lk >= 512) return qt2 ? launch_attn<T, D, 2, true, 128>(p, s) : launch_attn<T, D, 1, true, 128>(p, s);
+    }
+    return qt2 ? launch_attn<T, D, 2, true, 64>(p, s) : launch_attn<T, D, 1, true, 64>(p, s);
+  }
+  // v5 family (buffer-load K/V staging, one-time pad columns, no tail code for d = 40)
+  const bool v5_ok = (int64_t)p.lk * p.ldk * (int64_t)sizeof(T) < (1ll << 31) &&
+                     (int64_t)p.lk * p.ldv * (int64_t)sizeof(T) < (1ll << 31);
+  if (variant >= 5 && variant <= 12 && !v5_ok) return DD_ERR_UNSUPPORTED;
+  if (variant == 9) { if constexpr (D == 40) return launch_attn5<T, D, 2, 64, 1, 4>(p, s); }
+  if (variant == 10) { if constexpr (D == 40) return launch_attn5<T, D, 2, 128, 1, 4>(p, s); }
+  if (variant == 11) { if constexpr (D == 40) return launch_attn5<T, D, 3, 64, 1, 3>(p, s); }
+  if (variant == 12) { if constexpr (D == 40) return launch_attn5<T, D, 3, 128, 1, 3>(p, s); }
+  if (variant == 5) { if constexpr (D <= 80) return launch_attn5<T, D, 2, 128, 1>(p, s); }
+  if (variant == 6) { if constexpr (D <= 80) return launch_attn5<T, D, 2, 64, 2>(p, s); }
+  if (variant == 7) return launch_attn5<T, D, 2, 64, 1>(p, s);
+  if (variant == 8) return launch_attn5<T, D, 1, 64, 1>(p, s);
+  // Default: the v5 family whenever its 32-bit buffer offsets fit.
+  if (v5_ok) {
+    if constexpr (D == 40) {
+      // 32 or 48 query rows per wave (128 / 192 per workgroup).  The loop is VALU-issue-bound and only
+      // reaches that bound with the SIMDs full (4 waves at 32 rows, 3 at 48), so what decides is how
+      // evenly the workgroups fill the chip: 12 instances x 8 heads x 1400 rows is 1056 workgroups of
+      // 128 rows on 1024 slots (a second, nearly empty generation: 65 us) but 768 of 192 rows on 768
+      // slots (56 us).  Take the split with the smaller ceil(generations) / generations.
+      if (qt2) {
+        const double g2 = (double)((p.lq + 127) / 128) * p.batch * p.heads / 1024.0;
+        const double g3 = (double)((p.lq + 191) / 192) * p.batch * p.heads / 768.0;
+        auto waste = [](double g) { double c = (double)(long)g; if (c < g) c += 1.0; return c / g; };
+        if (waste(g3) < waste(g2) - 0.05)
+          return p.lk >= 512 ? launch_attn5<T, D, 3, 128, 1, 3>(p, s) : launch_attn5<T, D, 3, 64, 1, 3>(p, s);
+        return launch_attn5<T, D, 2, 64, 1>(p, s);
+      }
+      return launch_attn5<T, D, 1, 64, 1>(p, s);
+    } else if constexpr (D == 80) {
+      if (qt2) return p.lk >= 512 ? launch_attn5<T, D, 2, 128, 1>(p, s) : launch_attn5<T, D, 2, 64, 1>(p, s);
+      return launch_attn5<T, D, 1, 64, 1>(p, s);
+    } else {
+      return qt2 ? launch_attn5<T, D, 2, 64, 1>(p, s) : launch_attn5<T, D, 1, 64, 1>(p, s);
+    }
+  }
   if constexpr (D <= 80) {
     if (p.lk >= 512) return qt2 ? launch_attn<T, D, 2, true, 128>(p, s) : launch_attn<T, D, 1, true, 128>(p, s);
   }

@@ -359,7 +359,7 @@ ATTN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 8, 9, 11, 12, 13])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[str(c) for c in ATTN_CASES])
 def test_attention(ops, dtype, variant, case):
@@ -400,6 +400,54 @@ def test_attention_softmax_spike(ops):
     k[250] = q[7] * 4.0
     y = ops.attention(q, k, v, b, lq, lk, h, d)
     check(y, L.attention_ref(q, k, v, b, lq, lk, h, d), dtype, "attention spike", 4.0)
+
+
+@pytest.mark.parametrize("variant", [0, 5, 6, 7, 8, 11, 13])
+@pytest.mark.parametrize("lk", [1, 31, 33, 100, 129, 200])
+def test_attention_ragged_tail_all_scores_negative(ops, variant, lk):
+    """Keys past lk are zero rows in LDS and score exactly 0.  When every real score of a row is far
+    below 0 the padded keys would own the running max (and, without the zeroed ones column, the
+    denominator): the result must still be the softmax over the lk real keys only."""
+    b, lq, h, d = 2, 48, 8, 40
+    dtype = torch.bfloat16
+    q = rnd((b * lq, h * d), dtype, 1) + 1.5
+    k = -(rnd((b * lk, h * d), dtype, 2).abs() + 1.0) * 2.0       # q . k strongly negative everywhere
+    v = rnd((b * lk, h * d), dtype, 3)
+    y = ops.attention(q, k, v, b, lq, lk, h, d, variant=variant)
+    ref = L.attention_ref(q, k, v, b, lq, lk, h, d)
+    assert torch.isfinite(y.float()).all()
+    check(y, ref, dtype, "attention ragged tail lk=%d v%d" % (lk, variant), 4.0)
+
+
+@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_v5_fused_qkv_and_neighbours(ops, dtype, variant):
+    """The buffer-load staging with strided q/k/v views of one fused projection, kv_batch_map and
+    accumulate (attn4) — at d = 40 with a ragged last key tile."""
+    b, l, h, d = 6, 350, 8, 40
+    c = h * d
+    qkv = rnd((b * l, 3 * c), dtype, 1)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    left = torch.tensor([5, 0, 1, 2, 3, 4], dtype=torch.int32, device="cuda")
+    right = torch.tensor([1, 2, 3, 4, 5, 0], dtype=torch.int32, device="cuda")
+    out = ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left, variant=variant)
+    ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=right, out=out, accumulate=True, variant=variant)
+    ref = (L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=left)
+           + L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=right))
+    check(out, ref, dtype, "attn4 neighbour sum v%d" % variant, 6.0)
+
+
+@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+def test_attention_v5_softmax_spike(ops, variant):
+    b, lq, lk, h, d = 1, 64, 300, 8, 40
+    dtype = torch.float16
+    q = rnd((b * lq, h * d), dtype, 1)
+    k = rnd((b * lk, h * d), dtype, 2)
+    v = rnd((b * lk, h * d), dtype, 3)
+    k[250] = q[7] * 4.0
+    k[299] = q[9] * 4.0                     # spike inside the ragged last chunk
+    y = ops.attention(q, k, v, b, lq, lk, h, d, variant=variant)
+    check(y, L.attention_ref(q, k, v, b, lq, lk, h, d), dtype, "attention spike v%d" % variant, 4.0)
 
 
 # ----------------------------------------------------------------------- elementwise ----
