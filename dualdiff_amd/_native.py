@@ -72,6 +72,8 @@ SIGNATURES = {
     "dd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dd_timestep_embedding": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                         c_int32, c_void_p]),
+    "dd_cfg_unipc_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_float, c_int64, c_int32, c_void_p]),
     "dd_ors_project": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                  c_float, c_int32, c_int32, c_int32, c_void_p]),
     "dd_fourier_embed": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, POINTER(c_float), c_int32, c_int32,

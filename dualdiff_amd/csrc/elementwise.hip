@@ -203,6 +203,30 @@ void dd_cfg_ddim_kernel(const T* eps, const T* x, T* x_out, T* x_dup, const floa
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_cfg_unipc_kernel(const T* eps, const T* x, T* x_out, T* x_dup, float* last, float* m1, float* m2,
+                         const float* coef, float guidance, int64_t n) {
+  const float a_x = coef[0], a_e = coef[1], use_c = coef[2], c_l = coef[3], c_1 = coef[4], c_2 = coef[5],
+              c_0 = coef[6], p_x = coef[7], p_0 = coef[8], p_1 = coef[9];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float eu = (float)eps[i], ec = (float)eps[n + i];
+    const float e = (float)(T)(eu + guidance * (ec - eu));     // guided noise rounded to the model dtype
+    const float xv = (float)x[i];
+    const float x0 = a_x * xv + a_e * e;
+    const float o1 = m1[i];
+    float xc = xv;
+    if (use_c != 0.f) xc = c_l * last[i] + c_1 * o1 + c_2 * m2[i] + c_0 * x0;
+    const T r = (T)(p_x * xc + p_0 * x0 + p_1 * o1);
+    last[i] = xc;
+    m2[i] = o1;
+    m1[i] = x0;
+    x_out[i] = r;
+    if (x_dup) x_dup[i] = r;
+  }
+}
+
 inline unsigned grid_for(int64_t work, int per_block = 256, unsigned cap = 2048) {
   int64_t b = (work + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -395,6 +419,24 @@ extern "C" int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, voi
     hipLaunchKernelGGL(dd_cfg_ddim_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, s,
                        (const __bf16*)eps, (const __bf16*)x, (__bf16*)x_out, (__bf16*)x_dup,
                        coef, guidance, n);
+  return dd_check_launch();
+}
+
+extern "C" int dd_cfg_unipc_step(const void* eps, const void* x, void* x_out, void* x_dup, float* last,
+                                 float* m1, float* m2, const float* coef, float guidance, int64_t n,
+                                 int32_t dtype, dd_stream_t stream) {
+  if (!eps || !x || !x_out || !last || !m1 || !m2 || !coef || n <= 0) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_cfg_unipc_kernel<_Float16>, dim3(grid_for(n)), dim3(256), 0, s,
+                       (const _Float16*)eps, (const _Float16*)x, (_Float16*)x_out, (_Float16*)x_dup,
+                       last, m1, m2, coef, guidance, n);
+  else
+    hipLaunchKernelGGL(dd_cfg_unipc_kernel<__bf16>, dim3(grid_for(n)), dim3(256), 0, s,
+                       (const __bf16*)eps, (const __bf16*)x, (__bf16*)x_out, (__bf16*)x_dup,
+                       last, m1, m2, coef, guidance, n);
   return dd_check_launch();
 }
 

@@ -512,6 +512,21 @@ def cfg_ddim_step(eps, x, coef, guidance, x_out=None, x_dup=None):
     return x_out
 
 
+def cfg_unipc_step(eps, x, hist, coef, guidance, x_out=None, x_dup=None):
+    """eps: (2, n...) uncond first; x: (n...); hist: fp32 (3, n...) = [last, m1, m2] updated in place;
+    coef: fp32 device [10] (dualdiff_amd.pipeline.schedulers.unipc_schedule row)."""
+    lib = _native.load()
+    _need_gpu(eps, x, hist, coef, x_out, x_dup)
+    if hist.dtype != torch.float32 or hist.shape[0] != 3 or hist[0].numel() != x.numel() or not hist.is_contiguous():
+        raise ValueError("hist must be a contiguous fp32 (3, n...) tensor")
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    rc = lib.dd_cfg_unipc_step(_ptr(eps), _ptr(x), _ptr(x_out), _ptr(x_dup), _ptr(hist[0]), _ptr(hist[1]),
+                               _ptr(hist[2]), _ptr(coef), float(guidance), x.numel(), _dt(x), _stream())
+    _native.check(rc, "cfg_unipc_step")
+    return x_out
+
+
 def ors_project(occ, origin, direction, samples, step=0.2, *, want_labels=True, cond_dtype=None,
                 keep_fg=True, keep_bg=True):
     """ORS ray sampling (include/dualdiff_hip.h: dd_ors_project).  occ: (200, 200, 16) uint8 on the GPU;

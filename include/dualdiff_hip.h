@@ -249,6 +249,20 @@ int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, void* x_dup,
                      const float* coef, float guidance, int64_t n,
                      int32_t dtype, dd_stream_t stream);
 
+/* Classifier-free guidance + UniPC (bh2, order <= 2, x0-prediction) step, fused — the scheduler the
+ * reference's test pipeline installs (misc/test_utils.py:161-162) and steps at
+ * pipeline/pipeline_bev_controlnet.py:487-499:
+ *   eps = eps_u + g (eps_c - eps_u);  x0 = a_x x + a_e eps
+ *   x_c = use_c ? c_l last + c_1 m1 + c_2 m2 + c_0 x0 : x        (corrector)
+ *   x'  = p_x x_c + p_0 x0 + p_1 m1                              (predictor)
+ *   last <- x_c;  m2 <- m1;  m1 <- x0
+ * eps: [2][n] (uncond first), x / x_out / x_dup: [n] in dtype T; last, m1, m2: [n] fp32 history owned by
+ * the caller (any values on the first step: use_c = 0, p_1 = 0 there); coef: device fp32[10] =
+ * {a_x, a_e, use_c, c_l, c_1, c_2, c_0, p_x, p_0, p_1} read at kernel time (graph replay). */
+int dd_cfg_unipc_step(const void* eps, const void* x, void* x_out, void* x_dup, float* last, float* m1,
+                      float* m2, const float* coef, float guidance, int64_t n, int32_t dtype,
+                      dd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

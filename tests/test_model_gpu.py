@@ -367,3 +367,51 @@ def test_full_step_dual_branch_graph_vs_oracle(unet_case, cnet_case, dtype):
     # graph replay and hoisting must not change results at all
     assert torch.equal(outs[(True, False)], outs[(False, True)])
     assert max(e, e2) <= 1.0, rec          # no floor given: plain 1e-3 on the latents
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_unipc_denoiser_graph_equals_eager_and_restated_scheduler(unet_case, cnet_case, dtype):
+    """N4: BEVDenoiser(sampler="unipc") — HIP-graph replay reproduces the eager run bit for bit (the capture
+    warm-ups must not advance the multistep history), and the latents follow the restated UniPC scheduler
+    applied to the noise predictions the HIP model produced."""
+    from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
+    from oracle.unipc import UniPCRestated
+    usd = unet_case[0]
+    inp, refs = cnet_case
+    lat = bf16_round(seeded_tensor((1, 4, H, W), 78))[:, None].expand(-1, NCAM, -1, -1, -1).contiguous()
+    unet = UNet2DConditionModelMultiview(cross_attention_dim=768, neighboring_view_pair=PAIR)
+    unet.load_state_dict(usd)
+    unet = unet.to("cuda", dtype).eval()
+    cns = [_make_cnet(refs[False][0], False, dtype)]
+    nsteps, run = 20, 4
+    outs, eps_log = {}, []
+    for graph in (False, True):
+        den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=nsteps, use_graph=graph,
+                          sampler="unipc")
+        with torch.no_grad():
+            den.set_inputs(lat.cuda().to(dtype), _to_dev(inp["text"], dtype), _to_dev(inp["camera_param"], dtype),
+                           [_to_dev(inp["boxes_bg"], dtype)], [_to_dev(inp["cond_bg"], dtype)])
+            if not graph:
+                body = den._step_body
+
+                def logged():
+                    e = body()
+                    eps_log.append(e.float().cpu().clone().reshape(2, NCAM, 4, H, W))
+                    return e
+                den._step_body = logged
+            den.run(run)
+        outs[graph] = den.latents.float().cpu()
+    assert torch.equal(outs[True], outs[False])
+    assert len(eps_log) == run
+    sch = UniPCRestated()
+    ts = sch.set_timesteps(nsteps)
+    assert list(den.timesteps[:run]) == list(ts[:run])
+    x = lat.reshape(NCAM, 4, H, W).to(dtype).double()
+    for i in range(run):
+        e = eps_log[i]
+        guided = (e[0] + 2.0 * (e[1] - e[0])).to(dtype).double()
+        x = sch.step(guided, int(ts[i]), x).to(dtype).double()      # latents are stored in the model dtype
+    rec = []
+    err = report("unipc latents after %d steps" % run, outs[True].reshape(NCAM, 4, H, W), x.float(), dtype, rec)
+    assert err <= 1.0, rec

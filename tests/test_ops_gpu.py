@@ -492,6 +492,34 @@ def test_fails_loudly_on_cpu_tensor(ops):
         ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cfg_unipc_sequence(ops, dtype):
+    """dd_cfg_unipc_step over a whole 8-step UniPC run (warm-up, order-2 steps, lower-order final step)
+    against the step-by-step restatement fed with the same guided noise."""
+    from dualdiff_amd.pipeline.schedulers import unipc_schedule
+    from oracle.unipc import UniPCRestated
+    steps, n, g = 8, 6 * 4 * 28 * 50, 2.0
+    sch = UniPCRestated()
+    ts = sch.set_timesteps(steps)
+    _, tab = unipc_schedule(steps)
+    x = rnd((n,), dtype, 1)
+    hist = torch.zeros((3, n), dtype=torch.float32, device="cuda")
+    ref = x.float().cpu().double()
+    dup = torch.empty_like(x)
+    for i, t in enumerate(ts.tolist()):
+        eps = rnd((2, n), dtype, 10 + i)
+        e32 = eps.float().cpu()
+        guided = (e32[0] + g * (e32[1] - e32[0])).to(dtype).double()       # rounded like the kernel / reference
+        ref = sch.step(guided, t, ref)
+        x = ops.cfg_unipc_step(eps, x, hist, tab[i].cuda(), g, x_dup=dup)
+        assert torch.equal(x, dup)
+        # the kernel's sample is rounded to the storage type every step; follow it so errors do not compound
+        check(x, ref.float(), dtype, "cfg+unipc step %d" % i, 3.0)
+        ref = x.float().cpu().double()
+        sch.last_sample = hist[0].cpu().double()
+        sch.model_outputs = [hist[2].cpu().double(), hist[1].cpu().double()]
+
+
 # ------------------------------------------------------------------ ORS projection (N3) ----
 @torch.no_grad()
 def test_ors_projection_bit_exact_gpu():
