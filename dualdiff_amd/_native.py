@@ -31,7 +31,7 @@ class GemmDesc(Structure):
         ("hv", c_int32), ("wv", c_int32), ("hout", c_int32), ("wout", c_int32), ("stride", c_int32),
         ("dtype", c_int32), ("tile", c_int32), ("split_k", c_int32),
         ("ws", c_void_p), ("ws_bytes", c_int64),
-        ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("reserved0", c_int32),
+        ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32),
     ]
 
 
@@ -74,6 +74,7 @@ SIGNATURES = {
                                         c_int32, c_void_p]),
     "dd_cfg_unipc_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_int64, c_int32, c_void_p]),
+    "dd_softmax_rows": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int64, c_int32, c_void_p]),
     "dd_ors_project": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                  c_float, c_int32, c_int32, c_int32, c_void_p]),
     "dd_fourier_embed": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, POINTER(c_float), c_int32, c_int32,

@@ -118,6 +118,28 @@ void dd_ors_project_kernel(const uint8_t* __restrict__ occ, const float* __restr
   }
 }
 
+// one wave per row; the row is read twice (max+sum pass, write pass) — it sits in L2
+template <typename T>
+__global__ __launch_bounds__(256)
+void dd_softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, int64_t rows, int cols,
+                            int64_t lds, int64_t ldp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + row * lds;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, sr[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += __expf(sr[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.0f / sum;
+  T* pr = p + row * ldp;
+  for (int c = lane; c < ldp; c += 64) pr[c] = c < cols ? (T)(__expf(sr[c] - mx) * inv) : (T)0.f;
+}
+
 struct FourierFreqs { float f[16]; };
 
 template <typename TI, typename TO>
@@ -349,6 +371,20 @@ extern "C" int dd_ors_project(const uint8_t* occ, const float* origin, const flo
   else
     hipLaunchKernelGGL(dd_ors_project_kernel<__bf16>, dim3(g), dim3(256), 0, s, occ, origin, dir, labels,
                        (__bf16*)cond, n_cam, hw, samples, step, keep_fg, keep_bg);
+  return dd_check_launch();
+}
+
+extern "C" int dd_softmax_rows(const float* s, void* p, int64_t rows, int32_t cols, int64_t lds, int64_t ldp,
+                               int32_t dtype, dd_stream_t stream) {
+  if (!s || !p || rows <= 0 || cols <= 0 || lds < cols || ldp < cols) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
+  const unsigned g = (unsigned)((rows + 3) / 4);
+  if (dtype == DD_F16)
+    hipLaunchKernelGGL(dd_softmax_rows_kernel<_Float16>, dim3(g), dim3(256), 0, st, s, (_Float16*)p, rows, cols, lds, ldp);
+  else
+    hipLaunchKernelGGL(dd_softmax_rows_kernel<__bf16>, dim3(g), dim3(256), 0, st, s, (__bf16*)p, rows, cols, lds, ldp);
   return dd_check_launch();
 }
 

@@ -40,7 +40,19 @@ struct GemmParams {
   int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
   int* tile_counters;                    // split-K: per-tile arrival counters (in-kernel ordered reduction) or NULL
+  int out_f32;                           // store fp32 instead of T
 };
+
+template <typename T>
+__device__ __forceinline__ void store8(const GemmParams& p, int64_t row, int col, const float (&v)[8]) {
+  if (p.out_f32) {
+    float* o = reinterpret_cast<float*>(p.out) + row * p.ldc + col;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    dd_st16(reinterpret_cast<T*>(p.out) + row * p.ldc + col, dd_pack8<T>(v));
+  }
+}
 
 // --- epilogue on 8 consecutive output channels of one row --------------------------------
 template <typename T>
@@ -70,14 +82,13 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int row, in
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = dd_silu_f(v[i]);
   }
-  T* o = reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col;
   if (p.accumulate) {
     float b[8];
-    dd_unpack8<T>(dd_ld16(o), b);
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col), b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
-  dd_st16(o, dd_pack8<T>(v));
+  store8<T>(p, row, col, v);
 }
 
 // XCD-aware bijective remap of a 1-D block id (guide T1): blocks b, b+8, ... share an XCD;
@@ -311,7 +322,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += b[e];
           }
-          dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
+          store8<T>(p, row, col, v);
         }
       }
     }
@@ -1311,6 +1322,7 @@ int validate(const dd_gemm_desc* d) {
     }
   }
   if (d->epilogue != DD_EPI_NONE && d->epilogue != DD_EPI_GEGLU && d->epilogue != DD_EPI_SILU) return DD_ERR_BAD_ARG;
+  if (d->out_f32 && (d->epilogue == DD_EPI_GEGLU || d->accumulate)) return DD_ERR_UNSUPPORTED;
   if (d->epilogue == DD_EPI_GEGLU && (d->res || d->rowvec || d->accumulate || d->alpha != 1.0f)) return DD_ERR_UNSUPPORTED;
   return DD_OK;
 }
@@ -1376,7 +1388,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.w = d->w; p.bias = d->bias; p.rowvec = d->rowvec;
   p.rows_per_inst = d->rows_per_inst > 0 ? d->rows_per_inst : 1; p.ld_rowvec = d->ld_rowvec;
   p.res = d->res; p.ldres = d->ldres; p.out = d->out; p.ldc = d->ldc;
-  p.alpha = d->alpha; p.accumulate = d->accumulate;
+  p.alpha = d->alpha; p.accumulate = d->accumulate; p.out_f32 = d->out_f32;
   p.act = d->epilogue == DD_EPI_SILU ? DD_EPI_SILU : DD_EPI_NONE;
   p.hin = d->hin; p.win = d->win; p.cin = d->cin; p.hv = d->hv; p.wv = d->wv;
   p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;

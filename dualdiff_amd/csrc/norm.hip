@@ -488,7 +488,7 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
   const int c = c1 + c2;
   if (m <= 0 || hw <= 0 || groups <= 0 || groups > 64 || c1 <= 0) return DD_ERR_BAD_ARG;
   if ((c1 & 7) || (c2 & 7) || c % groups != 0 || c > GN_MAX_C) return DD_ERR_BAD_ARG;
-  if (c / groups < 8) return DD_ERR_UNSUPPORTED;   // a 16-B vector may span at most 2 groups
+  if (c / groups < 4) return DD_ERR_UNSUPPORTED;   // a 16-B vector may span at most 2 groups (4 channels each at least)
   if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(x1) || (x2 && !dd_aligned16(x2)) || !dd_aligned16(y) ||
       !dd_aligned16(gamma) || !dd_aligned16(beta)) return DD_ERR_BAD_ARG;

@@ -229,8 +229,9 @@ def _rows2d(t):
 
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
-         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None):
+         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
+    out_f32: the result is stored as fp32 (attention logits that feed a softmax).
 
     ln = (colsum_f32, bias_f32, eps): LayerNorm fold — `a` is the UN-normalised input, `w` the
     gamma-scaled weight; the kernel computes the row statistics itself (include/dualdiff_hip.h)."""
@@ -244,9 +245,13 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     if w.shape[1] != k or not w.is_contiguous():
         raise ValueError("weight must be contiguous [N, K=%d], got %s" % (k, tuple(w.shape)))
     n = n_w // 2 if epilogue == DD_EPI_GEGLU else n_w
+    odt = torch.float32 if out_f32 else a.dtype
     if out is None:
-        out = torch.empty((rows, n), dtype=a.dtype, device=a.device)
+        out = torch.empty((rows, n), dtype=odt, device=a.device)
+    elif out.dtype != odt:
+        raise TypeError("gemm: out must be %s" % odt)
     d = GemmDesc()
+    d.out_f32 = int(bool(out_f32))
     d.a = a.data_ptr(); d.lda = a.stride(0); d.k1 = a.shape[1]
     if a2 is not None:
         a2 = _rows2d(a2)
@@ -274,8 +279,9 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
             raise ValueError("ln fold vectors must be fp32 with %d entries" % n_w)
         d.ln_colsum, d.ln_bias, d.ln_eps = colsum.data_ptr(), lnb.data_ptr(), float(eps)
     if tile == 0 and split_k == 0:
-        d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None),
-                                      (rows, n), a.dtype, a.device, warm=(a, a2, res))
+        d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
+                                      + (("f32",) if out_f32 else ()),
+                                      (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
         ws = workspace(need, a.device)
@@ -525,6 +531,21 @@ def cfg_unipc_step(eps, x, hist, coef, guidance, x_out=None, x_dup=None):
                                _ptr(hist[2]), _ptr(coef), float(guidance), x.numel(), _dt(x), _stream())
     _native.check(rc, "cfg_unipc_step")
     return x_out
+
+
+def softmax_rows(s, dtype, pad_to=8):
+    """fp32 logits (rows, cols) -> probabilities in `dtype`, (rows, cols rounded up to `pad_to`) with zero
+    padding columns (the K dimension of the following P @ V GEMM must be a multiple of 8)."""
+    lib = _native.load()
+    _need_gpu(s)
+    if s.dtype != torch.float32 or s.dim() != 2 or s.stride(1) != 1:
+        raise ValueError("softmax_rows takes a row-major fp32 matrix")
+    rows, cols = s.shape
+    ldp = (cols + pad_to - 1) // pad_to * pad_to
+    p = torch.empty((rows, ldp), dtype=dtype, device=s.device)
+    code = DD_F16 if dtype == torch.float16 else DD_BF16
+    _native.check(lib.dd_softmax_rows(_ptr(s), _ptr(p), rows, cols, s.stride(0), ldp, code, _stream()), "softmax_rows")
+    return p
 
 
 def ors_project(occ, origin, direction, samples, step=0.2, *, want_labels=True, cond_dtype=None,

@@ -119,7 +119,8 @@ typedef struct dd_gemm_desc {
   const void* ln_colsum;   /* NULL = no fold */
   const void* ln_bias;
   float ln_eps;
-  int32_t reserved0;
+  int32_t out_f32;     /* 1: `out` is fp32 [rows][ldc] (attention logits of the VAE mid block, which must not be
+                          rounded to the storage type before the softmax); no GEGLU / accumulate */
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
@@ -229,6 +230,13 @@ int dd_fourier_embed(const void* x, void* out, int64_t rows, int32_t dims, const
 int dd_ors_project(const uint8_t* occ, const float* origin, const float* dir, uint8_t* labels, void* cond,
                    int32_t n_cam, int32_t hw, int32_t samples, float step, int32_t keep_fg, int32_t keep_bg,
                    int32_t dtype, dd_stream_t stream);
+
+/* Row softmax of fp32 logits into the storage type: p[r][c] = softmax_c(s[r][c]) for c < cols
+ * (diffusers AttnProcessor `get_attention_scores` with upcast_softmax — the single 512-wide head of
+ * the VAE decoder's mid-block attention, decode_latents pipeline_bev_controlnet.py:101-113).
+ * s: fp32 [rows][lds]; p: T [rows][ldp], columns cols..ldp-1 are zero-filled (K padding of the PV GEMM). */
+int dd_softmax_rows(const float* s, void* p, int64_t rows, int32_t cols, int64_t lds, int64_t ldp,
+                    int32_t dtype, dd_stream_t stream);
 
 /* conv3x3 with tiny Cout (conv_out 320->4): y NCHW fp32/T. x NHWC (rows, cin),
  * w [cout][9*cin]; writes y as NCHW (m, cout, h, w) in dtype T.

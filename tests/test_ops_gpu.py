@@ -330,7 +330,10 @@ def test_fourier_embed(ops, dtype, shape, nf, inc):
 @pytest.mark.parametrize("m,hw,c1,c2,silu,eps", [
     (3, 1400, 320, 0, True, 1e-5), (2, 350, 640, 0, False, 1e-6), (2, 91, 1280, 0, True, 1e-5),
     (2, 1400, 640, 320, True, 1e-5), (2, 350, 1280, 640, True, 1e-5), (3, 28, 1280, 1280, True, 1e-5),
-    (2, 91, 1280, 640, True, 1e-5), (1, 1400, 320, 320, True, 1e-5)])
+    (2, 91, 1280, 640, True, 1e-5), (1, 1400, 320, 320, True, 1e-5),
+    # VAE decoder sizes: 4 channels per group (a 16-B vector holds two whole groups), large images
+    (2, 240, 128, 0, True, 1e-6), (1, 89600, 128, 0, True, 1e-6), (2, 22400, 256, 0, True, 1e-6),
+    (2, 5600, 512, 0, False, 1e-6)])
 def test_groupnorm(ops, dtype, m, hw, c1, c2, silu, eps):
     x1 = rnd((m * hw, c1), dtype, 1) + 0.5
     x2 = rnd((m * hw, c2), dtype, 2, 2.0) if c2 else None
