@@ -31,7 +31,7 @@ class GemmDesc(Structure):
         ("hv", c_int32), ("wv", c_int32), ("hout", c_int32), ("wout", c_int32), ("stride", c_int32),
         ("dtype", c_int32), ("tile", c_int32), ("split_k", c_int32),
         ("ws", c_void_p), ("ws_bytes", c_int64),
-        ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32),
+        ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32), ("ln_stats_out", c_void_p), ("ln_stats_in", c_void_p),
     ]
 
 

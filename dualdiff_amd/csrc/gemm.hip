@@ -41,6 +41,8 @@ struct GemmParams {
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
   int* tile_counters;                    // split-K: per-tile arrival counters (in-kernel ordered reduction) or NULL
   int out_f32;                           // store fp32 instead of T
+  float* stat_out;                       // [rows][n/32][2] row sum / sum of squares of the stored values, or NULL
+  const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
 };
 
 template <typename T>
@@ -282,7 +284,8 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
       for (int t2 = 0; t2 < TMB; ++t2) {
         const int tm = tb + t2;
         const int row = row0 + tm * 16;
-        if (row >= row_end) continue;
+        float st_s = 0.f, st_q = 0.f;                      // row statistics of this lane's columns
+        if (row < row_end) {
 #pragma unroll
         for (int g8 = 0; g8 < NG; ++g8) {
           const int col = col0 + g8 * 8;
@@ -323,6 +326,25 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
             for (int e = 0; e < 8; ++e) v[e] += b[e];
           }
           store8<T>(p, row, col, v);
+          if (p.stat_out) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { st_s += v[e]; st_q += v[e] * v[e]; }
+          }
+        }
+        }
+        if constexpr (TN == 2 || TN == 4) {
+          if (p.stat_out) {              // uniform: every lane of the wave takes part in the shuffles
+            // a lane holds 4*TN columns of its row; 32-column groups are 4 (TN = 2) or 2 (TN = 4) lanes q
+            st_s += __shfl_xor(st_s, 16, 64);  st_q += __shfl_xor(st_q, 16, 64);
+            if (TN == 2) { st_s += __shfl_xor(st_s, 32, 64);  st_q += __shfl_xor(st_q, 32, 64); }
+            const int gcol = block_n0 + wave_n * (TN * 16) + (TN == 2 ? 0 : (q >> 1) * 32);
+            const bool writer = TN == 2 ? q == 0 : (q & 1) == 0;
+            if (writer && row < row_end && gcol < p.n) {
+              float* dst = p.stat_out + ((int64_t)row * (p.n >> 5) + (gcol >> 5)) * 2;
+              dst[0] = st_s;
+              dst[1] = st_q;
+            }
+          }
         }
       }
     }
@@ -727,7 +749,24 @@ void dd_gemm2_kernel(const GemmParams p) {
   // LayerNorm fold: row statistics of the block's A rows (K = 40 * lpr columns: lpr lanes share a
   // row, five 16-B vectors per lane), computed while the first stages are in flight.
   __shared__ float s_ln_mean[BM], s_ln_rstd[BM];
-  if (!CONV && p.ln_colsum) {
+  if (!CONV && p.ln_colsum && p.stat_in) {
+    // the producer of `a` left per-row partial sums (one pair per 32 columns): a few loads per row
+    const int parts = p.k >> 5;
+    const float inv_k = 1.0f / (float)p.k;
+    for (int r = tid; r < BM; r += NW * 64) {
+      const float* src = p.stat_in + (int64_t)min(block_m0 + r, p.rows - 1) * parts * 2;
+      float sum = 0.f, sq = 0.f;
+      for (int i = 0; i < parts; i += 2) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 2);
+        sum += v[0] + v[2];
+        sq += v[1] + v[3];
+      }
+      const float mean = sum * inv_k;
+      s_ln_mean[r] = mean;
+      s_ln_rstd[r] = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + p.ln_eps);
+    }
+    __syncthreads();
+  } else if (!CONV && p.ln_colsum) {
     const int lpr = p.k / 40;                           // 8 / 16 / 32 (host-checked)
     const int rpw = 64 / lpr;
     const int sub = lane & (lpr - 1);
@@ -1181,7 +1220,7 @@ Plan make_plan(const dd_gemm_desc* d) {
       if (split < 1) split = 1;
     }
   }
-  if (geglu || d->ln_colsum) split = 1;
+  if (geglu || d->ln_colsum || d->ln_stats_out) split = 1;
   if (split > nkt) split = nkt;
   int kts = ceil_div(nkt, split);
   split = ceil_div(nkt, kts);
@@ -1323,6 +1362,9 @@ int validate(const dd_gemm_desc* d) {
   }
   if (d->epilogue != DD_EPI_NONE && d->epilogue != DD_EPI_GEGLU && d->epilogue != DD_EPI_SILU) return DD_ERR_BAD_ARG;
   if (d->out_f32 && (d->epilogue == DD_EPI_GEGLU || d->accumulate)) return DD_ERR_UNSUPPORTED;
+  if (d->ln_stats_out && ((d->n & 31) || d->epilogue == DD_EPI_GEGLU || d->out_f32 || !dd_aligned16(d->ln_stats_out)))
+    return DD_ERR_UNSUPPORTED;
+  if (d->ln_stats_in && (!d->ln_colsum || !dd_aligned16(d->ln_stats_in))) return DD_ERR_BAD_ARG;
   if (d->epilogue == DD_EPI_GEGLU && (d->res || d->rowvec || d->accumulate || d->alpha != 1.0f)) return DD_ERR_UNSUPPORTED;
   return DD_OK;
 }
@@ -1389,6 +1431,8 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.rows_per_inst = d->rows_per_inst > 0 ? d->rows_per_inst : 1; p.ld_rowvec = d->ld_rowvec;
   p.res = d->res; p.ldres = d->ldres; p.out = d->out; p.ldc = d->ldc;
   p.alpha = d->alpha; p.accumulate = d->accumulate; p.out_f32 = d->out_f32;
+  p.stat_out = reinterpret_cast<float*>(d->ln_stats_out);
+  p.stat_in = reinterpret_cast<const float*>(d->ln_stats_in);
   p.act = d->epilogue == DD_EPI_SILU ? DD_EPI_SILU : DD_EPI_NONE;
   p.hin = d->hin; p.win = d->win; p.cin = d->cin; p.hv = d->hv; p.wv = d->wv;
   p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops as O
-from .layers import Attention, BasicTransformerBlock, LayerNorm, Linear
+from .layers import Attention, BasicTransformerBlock, LayerNorm, Linear, want_ln_stats
 
 
 def _ensure_kv_is_int(view_pair):
@@ -90,11 +90,11 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         nb = len(maps)
         if self.fold_connector:
             w, b = self._folded_out(nb)
-            h = O.gemm(o, w, b, res=h)
+            h = O.gemm(o, w, b, res=h, ln_stats=want_ln_stats())        # feeds norm3
         else:
             if "_pk_bias_nb" not in a.__dict__ or a.__dict__["_pk_bias_nb"][0] != nb:
                 a.__dict__["_pk_bias_nb"] = (nb, (a.to_out[0].bias.detach().float() * nb).to(a.to_out[0].bias.dtype))
             y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
-            h = self.connector.run(y, res=h)
+            h = self.connector.run(y, res=h, ln_stats=want_ln_stats())
         # ---- feed-forward ------------------------------------------------------------------
         return self.ff.run(h, res=h, norm=self.norm3)

@@ -87,7 +87,7 @@ class Linear(_Cached):
 
     def run_ln(self, x2d, norm, **kw):
         """LayerNorm(norm) + this Linear as one GEMM on the UN-normalised x2d (fold_layernorm)."""
-        if not ln_fold_ok(norm, self.in_features, self.out_features):
+        if not ln_fold_ok(norm, self.in_features, self.out_features, x2d):
             return self.run(norm.run(x2d), **kw)
         w, ln = fold_layernorm(self.__dict__, "_pk_ln", norm, [self.weight], [self.bias])
         return O.gemm(x2d, w, None, ln=ln, **kw)
@@ -173,14 +173,28 @@ class LayerNorm(nn.Module):
 # config 2, folding all four norms (QKV is 3C wide, the GEGLU projection 8C) LOSES 5 % (72.8 -> 68.9
 # steps/s), folding only the C-wide to_q of attn2 is neutral (73.1 vs 73.1-75).  Off by default;
 # DD_LN_FOLD=all / q turn it on.
+#
+# DD_LN_FOLD=stats: fold wherever the producer of the input left its row statistics behind
+# (`O.gemm(..., ln_stats=True)`: proj_in and the to_out + residual GEMMs have every output value in
+# registers), so that the consumer reads k/32 partial sums per row instead of the rows themselves and the
+# LayerNorm launch disappears.  Measured on config 2: 81.1-81.3 vs 82.0 steps/s with the fold off — the
+# extra epilogue work of the wide consumers (QKV 3C, GEGLU 8C: two FMAs and two table loads per output
+# value) and the producers' shuffles cost more than 106 small LayerNorm launches that mostly overlap
+# with other streams.  Kept behind the switch, with kernel tests.
 LN_FOLD = __import__("os").environ.get("DD_LN_FOLD", "0")
 
 
-def ln_fold_ok(norm, k, n=None):
+def ln_fold_ok(norm, k, n=None, x=None):
     """The kernel-side fold covers the transformer widths of this network."""
     if LN_FOLD == "0" or not isinstance(norm, LayerNorm) or k not in (320, 640, 1280):
         return False
+    if LN_FOLD == "stats":
+        return x is not None and getattr(x, "_ln_stats", None) is not None
     return LN_FOLD == "all" or (n is not None and n <= k)
+
+
+def want_ln_stats():
+    return LN_FOLD == "stats"
 
 
 def fold_layernorm(cache, key, norm, weights, biases):
@@ -350,7 +364,7 @@ class Attention(_Cached):
         """One GEMM for Q, K, V of a self-attention style layer -> (rows, 3*inner).  With `norm`,
         x2d is the un-normalised input and the LayerNorm is folded into the GEMM."""
         if norm is not None:
-            if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim):
+            if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim, x2d):
                 return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")))
             mods = (self.to_q, self.to_k, self.to_v)
             w, ln = fold_layernorm(self.__dict__, "_pk_ln_qkv", norm, [m.weight for m in mods], [m.bias for m in mods])
@@ -361,14 +375,14 @@ class Attention(_Cached):
         """K and V of the context in one GEMM -> (rows_ctx, 2*inner)."""
         return O.gemm(ctx2d, self._fused(("to_k", "to_v")))
 
-    def run_self(self, x2d, batch, lq, res=None, norm=None):
+    def run_self(self, x2d, batch, lq, res=None, norm=None, ln_stats=False):
         c = self.inner_dim
         qkv = self.project_qkv(x2d, norm)
         o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, lq, lq, self.heads,
                         self.dim_head, self.scale)
-        return self.to_out[0].run(o, res=res)
+        return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
 
-    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None):
+    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None, ln_stats=False):
         c = self.inner_dim
         q = self.to_q.run(x2d) if norm is None else self.to_q.run_ln(x2d, norm)
         pre = self.__dict__.pop("_kv_prefetched", None)
@@ -381,7 +395,7 @@ class Attention(_Cached):
         if kv is None:
             kv = self.project_kv(ctx2d)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale)
-        return self.to_out[0].run(o, res=res)
+        return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
@@ -445,14 +459,15 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def _attn(self, attn, norm, h, batch, l, ctx=None, lc=0):
+    def _attn(self, attn, norm, h, batch, l, ctx=None, lc=0, ln_next=True):
         """LayerNorm `norm` + `attn` (+ residual h).  The built-in processor folds the LayerNorm
         into the Q(KV) projection and the residual into the out-projection; foreign processors get
         the normalised (B, L, C) tensor through the diffusers protocol."""
         if isinstance(attn.processor, HIPAttnProcessor):
+            st = ln_next and want_ln_stats()          # the output feeds the block's next LayerNorm
             if ctx is None:
-                return attn.run_self(h, batch, l, res=h, norm=norm)
-            return attn.run_cross(h, batch, l, ctx, lc, res=h, norm=norm)
+                return attn.run_self(h, batch, l, res=h, norm=norm, ln_stats=st)
+            return attn.run_cross(h, batch, l, ctx, lc, res=h, norm=norm, ln_stats=st)
         e = None if ctx is None else ctx.reshape(batch, lc, -1)
         out = attn(norm.run(h).reshape(batch, l, -1), encoder_hidden_states=e)
         return O.add(out.reshape(batch * l, -1).contiguous(), h)
@@ -479,7 +494,7 @@ class Transformer2DModel(nn.Module):
 
     def run(self, x, m, h, w, ctx2d, lc):
         a = self.norm.run(x, m, h * w, False)
-        t = self.proj_in.run(a)
+        t = self.proj_in.run(a, ln_stats=want_ln_stats())
         for blk in self.transformer_blocks:
             t = blk.run(t, m, h * w, ctx2d, lc)
         return self.proj_out.run(t, res=x)

@@ -229,14 +229,18 @@ def _rows2d(t):
 
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
-         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False):
+         out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
+         ln_stats=False):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
     out_f32: the result is stored as fp32 (attention logits that feed a softmax).
+    ln_stats: the epilogue also leaves per-row partial sums of the output (n % 32 == 0) as `out._ln_stats`;
+    a later gemm(out, ..., ln=...) picks them up instead of recomputing the row statistics.
 
     ln = (colsum_f32, bias_f32, eps): LayerNorm fold — `a` is the UN-normalised input, `w` the
     gamma-scaled weight; the kernel computes the row statistics itself (include/dualdiff_hip.h)."""
     lib = _native.load()
     _need_gpu(a, w, bias, a2, res, rowvec, out)
+    stats_in = getattr(a, "_ln_stats", None) if ln is not None else None
     a = _rows2d(a)
     w = _rows2d(w)
     rows = a.shape[0]
@@ -278,9 +282,20 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         if colsum.dtype != torch.float32 or lnb.dtype != torch.float32 or colsum.numel() != n_w or lnb.numel() != n_w:
             raise ValueError("ln fold vectors must be fp32 with %d entries" % n_w)
         d.ln_colsum, d.ln_bias, d.ln_eps = colsum.data_ptr(), lnb.data_ptr(), float(eps)
+        if stats_in is not None:
+            if tuple(stats_in.shape) != (rows, k // 32, 2) or stats_in.dtype != torch.float32:
+                raise ValueError("stale LayerNorm statistics attached to the input")
+            d.ln_stats_in = stats_in.data_ptr()
+    stats_out = None
+    if ln_stats:
+        if n % 32 or epilogue == DD_EPI_GEGLU or out_f32:
+            raise ValueError("ln_stats needs a plain epilogue and n % 32 == 0")
+        stats_out = torch.empty((rows, n // 32, 2), dtype=torch.float32, device=a.device)
+        d.ln_stats_out = stats_out.data_ptr()
     if tile == 0 and split_k == 0:
         d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
-                                      + (("f32",) if out_f32 else ()),
+                                      + (("f32",) if out_f32 else ()) + (("so",) if ln_stats else ())
+                                      + (("si",) if stats_in is not None else ()),
                                       (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
@@ -292,8 +307,10 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         _TIMER.stop(e0, _kname(lib, d) + (" gemm %dx%dx%d" % (rows, n_w, k) if _TIMER.shapes else ""),
                     2.0 * rows * n_w * k,
                     2.0 * (rows * k + n_w * k + rows * n * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))))
-        return out
-    _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
+    else:
+        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
+    if stats_out is not None:
+        out._ln_stats = stats_out
     return out
 
 

@@ -121,6 +121,15 @@ typedef struct dd_gemm_desc {
   float ln_eps;
   int32_t out_f32;     /* 1: `out` is fp32 [rows][ldc] (attention logits of the VAE mid block, which must not be
                           rounded to the storage type before the softmax); no GEGLU / accumulate */
+  /* LayerNorm statistics carried from the producer to the consumer (both optional, fp32):
+   * ln_stats_out: this GEMM's epilogue also writes, per output row and per 32-column group, the sum and the
+   *   sum of squares of the values it stores: [rows][n / 32][2] (n % 32 == 0, no split-K, no GEGLU).  Every
+   *   transformer-block GEMM whose output feeds a LayerNorm (proj_in, to_out + residual; blocks.py:150-236)
+   *   holds those values in registers anyway.
+   * ln_stats_in: with the LayerNorm fold above, the row mean / rstd come from such a table of the `a`
+   *   tensor ([rows][k / 32][2]) instead of a pass over the rows in every column tile's prologue. */
+  void* ln_stats_out;
+  const void* ln_stats_in;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);

@@ -241,6 +241,51 @@ def test_gemm_layernorm_fold_geglu(ops, tile):
     check(y, ref, dtype, "geglu + LN fold tile%d" % tile, 3.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,c,tile", [(16800, 320, 0), (4200, 640, 17), (1092, 1280, 15), (336, 1280, 11),
+                                         (700, 320, 26), (129, 640, 14), (37, 320, 1), (350, 640, 4)])
+def test_gemm_ln_stats_producer_consumer(ops, dtype, rows, c, tile):
+    """The epilogue of a C x C projection (+ residual) leaves per-row partial sums of what it stores; the
+    next GEMM evaluates LayerNorm(h) W^T + b from them (`ln_stats` -> `_ln_stats` -> `ln=`) — against
+    Linear -> + res -> LayerNorm -> Linear of the reference."""
+    a = rnd((rows, c), dtype, 1)
+    w1 = rnd((c, c), dtype, 2, c ** -0.5)
+    b1 = rnd((c,), dtype, 3)
+    res = (rnd((rows, c), dtype, 4).float() * (0.5 + rnd((rows, 1), torch.float32, 7).abs()) + 0.6).to(dtype)
+    h = ops.gemm(a, w1, b1, res=res, ln_stats=True, tile=tile)
+    st = h._ln_stats
+    assert st.shape == (rows, c // 32, 2) and st.dtype == torch.float32
+    hf = h.float().cpu().reshape(rows, c // 32, 32)
+    # statistics are taken from the fp32 values before the store rounding: compare at storage precision
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    s_ref, q_ref = hf.sum(-1), (hf * hf).sum(-1)
+    assert (st[..., 0].cpu() - s_ref).abs().max().item() <= tol * hf.abs().sum(-1).max().item()
+    assert (st[..., 1].cpu() - q_ref).abs().max().item() <= 2 * tol * q_ref.max().item()
+    # consumer
+    n = 3 * c
+    w2 = rnd((n, c), dtype, 5, c ** -0.5)
+    b2 = rnd((n,), dtype, 6)
+    gamma = (1.0 + 0.2 * rnd((c,), torch.float32, 8)).to(dtype)
+    beta = (0.1 * rnd((c,), torch.float32, 9)).to(dtype)
+    wp, colsum, lnb = _ln_fold(w2, b2, gamma, beta, dtype)
+    y = ops.gemm(h, wp, None, ln=(colsum, lnb, 1e-5))
+    ref = L.linear_ref(L.layernorm_ref(h, gamma, beta, 1e-5), w2, b2)
+    check(y, ref, dtype, "LN stats producer->consumer %dx%d tile%d" % (rows, c, tile), 2.0)
+    # the in-kernel statistics of the same input give the same result up to the statistics' rounding
+    h2 = h.clone()
+    y2 = ops.gemm(h2, wp, None, ln=(colsum, lnb, 1e-5))
+    check(y2, ref, dtype, "LN fold in-kernel stats", 2.0)
+
+
+def test_gemm_ln_stats_rejects(ops):
+    dtype = torch.bfloat16
+    a = rnd((64, 320), dtype, 1)
+    with pytest.raises(ValueError):
+        ops.gemm(a, rnd((48, 320), dtype, 2), None, ln_stats=True)            # n % 32 != 0
+    with pytest.raises(ValueError):
+        ops.gemm(a, rnd((640, 320), dtype, 2), None, ln_stats=True, epilogue=ops.DD_EPI_GEGLU)
+
+
 def test_gemm_layernorm_fold_rejects(ops):
     dtype = torch.bfloat16
     x = rnd((64, 512), dtype, 1)
