@@ -136,7 +136,7 @@ def _metric_name():
 
 def _mangled_fragment(kernel):
     """'dd_gemm2_kernel<__bf16, 2, 2, 4, 4, 2, true, false>' -> 'dd_gemm2_kernelIDF16bLi2ELi2ELi4ELi4ELi2ELb1ELb0EE'
-    (rocprofv3 prints most of our symbols mangled); 'dd_attn_kernel<bf16,D40>' -> 'dd_attn_kernelIDF16bLi40E'."""
+    (rocprofv3 prints most of our symbols mangled); 'dd_attn5_kernel<bf16,D40>' -> 'dd_attn5_kernelIDF16bLi40E'."""
     import re
     m = re.match(r"(\w+)<(.*)>", kernel)
     if not m:
@@ -276,6 +276,7 @@ def main():
         roofline = None
         if rank == 0 and not args.no_roofline:
             timer = O.KernelTimer()
+            timer.calibrate()                 # empty-bracket event overhead, subtracted per launch
             O.set_timer(timer)
             par = den.parallel_branches
             den.parallel_branches = False     # one stream: event pairs must not see co-running branches
@@ -292,6 +293,7 @@ def main():
             hbm_bound = d["flops"] / max(d["bytes"], 1.0) < ridge
             roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
                         "launches_per_step": d["count"], "avg_us": avg_s * 1e6,
+                        "event_overhead_us_subtracted": timer.overhead_ms * 1e3,
                         "share_of_timed_kernels": d["ms"] / sum(v["ms"] for v in summ.values()),
                         "achieved": gbps if hbm_bound else tflops,
                         "peak": PEAK_HBM_GBPS if hbm_bound else PEAK_MFMA_TFLOPS,
