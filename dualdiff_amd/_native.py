@@ -32,6 +32,7 @@ class GemmDesc(Structure):
         ("dtype", c_int32), ("tile", c_int32), ("split_k", c_int32),
         ("ws", c_void_p), ("ws_bytes", c_int64),
         ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32), ("ln_stats_out", c_void_p), ("ln_stats_in", c_void_p),
+        ("out_headmajor_d", c_int32), ("hm_scaled_planes", c_int32), ("hm_scale", c_float),
     ]
 
 
@@ -45,6 +46,8 @@ class AttnDesc(Structure):
         ("scale", c_float),
         ("kv_batch_map", c_void_p),
         ("accumulate", c_int32), ("dtype", c_int32), ("variant", c_int32),
+        ("q_head_stride", c_int64), ("k_head_stride", c_int64), ("v_head_stride", c_int64),
+        ("q_prescaled", c_int32),
     ]
 
 

@@ -30,6 +30,8 @@ struct AttnParams {
   const int32_t* kv_map;
   int accumulate;
   int nqb;             // q-blocks per (batch, head), filled by the launcher
+  int64_t qhs, khs, vhs;   // head strides (elements)
+  int prescaled;           // q carries scale * log2(e)
 };
 
 
@@ -81,9 +83,9 @@ void dd_attn_kernel(const AttnParams p) {
   const int kb = p.kv_map ? p.kv_map[b] : b;
   const int q0 = (qb * 4 + wave) * (QT * 16);
 
-  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * D;
-  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * D;
-  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * D;
+  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * p.qhs;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * p.khs;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * p.vhs;
 
   // ---- Q fragments (B operand of S^T = K Q^T), kept in registers -----------------------
   V8 qf[QT][KSTEPS];
@@ -301,7 +303,10 @@ void dd_attn_kernel(const AttnParams p) {
 //    numerator or the denominator.  Only the running max must not see them, and that is handled
 //    inside the (rare) rescale branch; the common path has no tail code at all;
 //  * NBUF = 2: two LDS tiles, one barrier per tile instead of two.
-template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE>
+// PRE: q arrives pre-multiplied by scale * log2(e) (dd_gemm_desc.hm_scale), so the scores leave the QK^T
+// MFMA in log2 units — and with the running max negated in the MFMA's C operand they leave it already
+// shifted: p = exp2(acc), no per-score FMA (16 of the ~70 VALU instructions per 32-key chunk).
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE, bool PRE>
 __global__ __launch_bounds__(256, WPE)
 void dd_attn5_kernel(const AttnParams p) {
   using V8 = typename dd_vec<T>::v8;
@@ -341,9 +346,9 @@ void dd_attn5_kernel(const AttnParams p) {
   const int kb = p.kv_map ? p.kv_map[b] : b;
   const int q0 = (qb * 4 + wave) * (QT * 16);
 
-  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * D;
-  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * D;
-  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * D;
+  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * p.qhs;
+  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * p.khs;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * p.vhs;
   const uint32_t k_row_bytes = (uint32_t)p.ldk * sizeof(T), v_row_bytes = (uint32_t)p.ldv * sizeof(T);
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(kbase), 0, (uint32_t)(p.lk - 1) * k_row_bytes + D * sizeof(T), 0x00020000);
@@ -400,7 +405,10 @@ void dd_attn5_kernel(const AttnParams p) {
     for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int j = 0; j < QT; ++j) { m_run[j] = -1e30f; l_run[j] = 0.f; }
+  for (int j = 0; j < QT; ++j) { m_run[j] = PRE ? 0.f : -1e30f; l_run[j] = 0.f; }
+  f32x4 cinit[QT];                       // PRE: -m_run broadcast, the C operand of the first QK^T MFMA
+#pragma unroll
+  for (int j = 0; j < QT; ++j) cinit[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 kreg[PER], vreg[PER];
   auto load_kv = [&](int tile0) {
@@ -451,7 +459,8 @@ void dd_attn5_kernel(const AttnParams p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int j = 0; j < QT; ++j)
-            sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[t][j]);
+            sacc[t][j] = dd_mfma16(kf[t], qf[j][ks],
+                                   ks == 0 ? (PRE ? cinit[j] : f32x4{0.f, 0.f, 0.f, 0.f}) : sacc[t][j]);
       }
       const bool tail = key0 + 32 > p.lk;             // uniform
       V8 pf[QT];
@@ -474,35 +483,71 @@ void dd_attn5_kernel(const AttnParams p) {
         if (!ONES && tail) mask_tail();
         float mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
                            fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {
-          if (ONES && tail) {          // the padded keys scored 0: keep them out of the running max
-            mask_tail();
-            mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
-                         fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-          }
-          float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-          const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
-          const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
-          m_run[j] = m_new;
-          if (!ONES) l_run[j] *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < DVT; ++dt) {
-            oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
-            oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
-          }
-        }
-        const float m_use = m_run[j];
-        float ls = 0.f;
         V8 pv;
+        if constexpr (PRE) {
+          // s is already (score - m_run) in log2 units.  The very first chunk of a row always takes the
+          // branch (m_run = 0 there is not a maximum yet and may be far above the scores).
+          const bool first = it == 0 && cc == 0;
+          if (first || __any(mx_l > RESCALE_THR)) {
+            if (ONES && tail) {
+              mask_tail();
+              mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
+                           fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            }
+            float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (!first) mx = fmaxf(mx, 0.f);              // the running max never decreases
+            mx = fmaxf(mx, -1e30f);                        // a fully masked row keeps a finite max
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-mx);
+            m_run[j] += mx;
+            cinit[j] = f32x4{-m_run[j], -m_run[j], -m_run[j], -m_run[j]};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], p.scale_log2, -m_use));
-          if (!ONES) ls += pe;
-          pv[e] = (T)pe;
+            for (int e = 0; e < 8; ++e) s[e] -= mx;
+            if (!ONES) l_run[j] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt) {
+              oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
+              oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
+            }
+          }
+          float ls = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(s[e]);
+            if (!ONES) ls += pe;
+            pv[e] = (T)pe;
+          }
+          if (!ONES) l_run[j] += ls;
+        } else {
+          if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {
+            if (ONES && tail) {          // the padded keys scored 0: keep them out of the running max
+              mask_tail();
+              mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
+                           fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            }
+            float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+            m_run[j] = m_new;
+            if (!ONES) l_run[j] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt) {
+              oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
+              oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
+            }
+          }
+          const float m_use = m_run[j];
+          float ls = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], p.scale_log2, -m_use));
+            if (!ONES) ls += pe;
+            pv[e] = (T)pe;
+          }
+          if (!ONES) l_run[j] += ls;
         }
         pf[j] = pv;
-        if (!ONES) l_run[j] += ls;
       }
 #pragma unroll
       for (int dt = 0; dt < DVT; ++dt) {
@@ -552,8 +597,8 @@ void dd_attn5_kernel(const AttnParams p) {
   }
 }
 
-template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE = 1>
-int launch_attn5(const AttnParams& p, hipStream_t s) {
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE, bool PRE>
+int launch_attn5p(const AttnParams& p, hipStream_t s) {
   constexpr int DQ = (D + 31) / 32 * 32;
   constexpr int DVT = (D + 15) / 16;
   constexpr size_t smem = (size_t)NBUF * KV_TILE * ((DQ + 16) + (DVT * 16 + (D == 160 ? 16 : 0))) * sizeof(T);
@@ -561,13 +606,19 @@ int launch_attn5(const AttnParams& p, hipStream_t s) {
   AttnParams pp = p;
   pp.nqb = (p.lq + qblk - 1) / qblk;
   dim3 grid(pp.nqb * p.batch * p.heads);
-  auto kern = dd_attn5_kernel<T, D, QT, KV_TILE, NBUF, WPE>;
+  auto kern = dd_attn5_kernel<T, D, QT, KV_TILE, NBUF, WPE, PRE>;
   if (smem > 65536) {
     static bool once = false;       // per instantiation
     if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; }
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, pp);
   return dd_check_launch();
+}
+
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE = 1>
+int launch_attn5(const AttnParams& p, hipStream_t s) {
+  if (p.prescaled) return launch_attn5p<T, D, QT, KV_TILE, NBUF, WPE, true>(p, s);
+  return launch_attn5p<T, D, QT, KV_TILE, NBUF, WPE, false>(p, s);
 }
 
 template <typename T, int D, int QT, bool TR, int KV_TILE>
@@ -627,7 +678,9 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
         const double g3 = (double)((p.lq + 191) / 192) * p.batch * p.heads / 768.0;
         auto waste = [](double g) { double c = (double)(long)g; if (c < g) c += 1.0; return c / g; };
         if (waste(g3) < waste(g2) - 0.05)
-          return p.lk >= 512 ? launch_attn5<T, D, 3, 128, 1, 3>(p, s) : launch_attn5<T, D, 3, 64, 1, 3>(p, s);
+          // (the prescaled-q variant of the 128-key tile spills at 48 rows per wave: 64-key tiles there)
+          return p.lk >= 512 && !p.prescaled ? launch_attn5<T, D, 3, 128, 1, 3>(p, s)
+                                             : launch_attn5<T, D, 3, 64, 1, 3>(p, s);
         return launch_attn5<T, D, 2, 64, 1>(p, s);
       }
       return launch_attn5<T, D, 1, 64, 1>(p, s);
@@ -674,6 +727,12 @@ extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
   p.batch = d->batch; p.heads = d->heads; p.lq = d->lq; p.lk = d->lk;
   p.scale_log2 = d->scale * 1.44269504088896340736f;
   p.kv_map = d->kv_batch_map; p.accumulate = d->accumulate;
+  p.qhs = d->q_head_stride ? d->q_head_stride : d->head_dim;
+  p.khs = d->k_head_stride ? d->k_head_stride : d->head_dim;
+  p.vhs = d->v_head_stride ? d->v_head_stride : d->head_dim;
+  if ((p.qhs & 7) || (p.khs & 7) || (p.vhs & 7)) return DD_ERR_BAD_ARG;
+  p.prescaled = d->q_prescaled ? 1 : 0;
+  if (d->q_prescaled) p.scale_log2 = 1.0f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();
   if (d->dtype == DD_F16) return launch_attn_t<_Float16>(d, p, s);

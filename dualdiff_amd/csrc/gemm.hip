@@ -43,10 +43,21 @@ struct GemmParams {
   int out_f32;                           // store fp32 instead of T
   float* stat_out;                       // [rows][n/32][2] row sum / sum of squares of the stored values, or NULL
   const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
+  int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
 };
 
 template <typename T>
-__device__ __forceinline__ void store8(const GemmParams& p, int64_t row, int col, const float (&v)[8]) {
+__device__ __forceinline__ void store8(const GemmParams& p, int64_t row, int col, float (&v)[8]) {
+  if (p.hm_d) {                            // one [rows][D] plane per head; the Q planes carry the softmax scale
+    const int plane = col / p.hm_d;
+    if (plane < p.hm_planes) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.hm_scale;
+    }
+    dd_st16(reinterpret_cast<T*>(p.out) + ((int64_t)plane * p.rows + row) * p.hm_d + (col - plane * p.hm_d),
+            dd_pack8<T>(v));
+    return;
+  }
   if (p.out_f32) {
     float* o = reinterpret_cast<float*>(p.out) + row * p.ldc + col;
     *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -1220,7 +1231,7 @@ Plan make_plan(const dd_gemm_desc* d) {
       if (split < 1) split = 1;
     }
   }
-  if (geglu || d->ln_colsum || d->ln_stats_out) split = 1;
+  if (geglu || d->ln_colsum || d->ln_stats_out || d->out_headmajor_d) split = 1;
   if (split > nkt) split = nkt;
   int kts = ceil_div(nkt, split);
   split = ceil_div(nkt, kts);
@@ -1365,6 +1376,10 @@ int validate(const dd_gemm_desc* d) {
   if (d->ln_stats_out && ((d->n & 31) || d->epilogue == DD_EPI_GEGLU || d->out_f32 || !dd_aligned16(d->ln_stats_out)))
     return DD_ERR_UNSUPPORTED;
   if (d->ln_stats_in && (!d->ln_colsum || !dd_aligned16(d->ln_stats_in))) return DD_ERR_BAD_ARG;
+  if (d->out_headmajor_d) {
+    if (d->out_headmajor_d < 8 || (d->out_headmajor_d & 7) || d->n % d->out_headmajor_d) return DD_ERR_BAD_ARG;
+    if (d->conv || d->epilogue == DD_EPI_GEGLU || d->accumulate || d->out_f32 || d->ln_stats_out) return DD_ERR_UNSUPPORTED;
+  }
   if (d->epilogue == DD_EPI_GEGLU && (d->res || d->rowvec || d->accumulate || d->alpha != 1.0f)) return DD_ERR_UNSUPPORTED;
   return DD_OK;
 }
@@ -1433,6 +1448,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.alpha = d->alpha; p.accumulate = d->accumulate; p.out_f32 = d->out_f32;
   p.stat_out = reinterpret_cast<float*>(d->ln_stats_out);
   p.stat_in = reinterpret_cast<const float*>(d->ln_stats_in);
+  p.hm_d = d->out_headmajor_d; p.hm_planes = d->hm_scaled_planes; p.hm_scale = d->hm_scale;
   p.act = d->epilogue == DD_EPI_SILU ? DD_EPI_SILU : DD_EPI_NONE;
   p.hin = d->hin; p.win = d->win; p.cin = d->cin; p.hv = d->hv; p.wv = d->wv;
   p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops as O
+from . import layers
 from .layers import Attention, BasicTransformerBlock, LayerNorm, Linear, want_ln_stats
 
 
@@ -81,12 +82,15 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         # ---- neighbour-view attention ------------------------------------------------------
         a = self.attn4
         c = a.inner_dim
-        qkv = a.project_qkv(h, self.norm4)
+        hm = layers.HEAD_MAJOR and a.to_q.bias is None
+        qkv = a.project_qkv(h, self.norm4, head_major=hm)
+        q, k, v = ((qkv[:a.heads], qkv[a.heads:2 * a.heads], qkv[2 * a.heads:]) if hm
+                   else (qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]))
         maps = self.neighbour_maps(batch, h.device)
         o = None
         for j, mp in enumerate(maps):
-            o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, l, l, a.heads, a.dim_head,
-                            a.scale, kv_batch_map=mp, out=o, accumulate=j > 0)
+            o = O.attention(q, k, v, batch, l, l, a.heads, a.dim_head, a.scale, kv_batch_map=mp, out=o,
+                            accumulate=j > 0, q_prescaled=hm)
         nb = len(maps)
         if self.fold_connector:
             w, b = self._folded_out(nb)

@@ -197,6 +197,11 @@ def want_ln_stats():
     return LN_FOLD == "stats"
 
 
+# Head-major Q / K / V planes + softmax scale folded into Q by the projection epilogue (dd_gemm_desc.
+# out_headmajor_d, dd_attn_desc.q_prescaled).  DD_ATTN_HEAD_MAJOR=0 restores the fused row-major layout.
+HEAD_MAJOR = __import__("os").environ.get("DD_ATTN_HEAD_MAJOR", "1") != "0"
+
+
 def fold_layernorm(cache, key, norm, weights, biases):
     """LayerNorm(x) @ W^T + b  ==  rstd * (x @ W'^T - mean * colsum) + b'   with
     W' = W * gamma, colsum[n] = sum_k W'[n,k] (of the ROUNDED W', the matrix the kernel multiplies by),
@@ -360,31 +365,47 @@ class Attention(_Cached):
     def _drop_cache(self):
         super()._drop_cache()
 
-    def project_qkv(self, x2d, norm=None):
-        """One GEMM for Q, K, V of a self-attention style layer -> (rows, 3*inner).  With `norm`,
-        x2d is the un-normalised input and the LayerNorm is folded into the GEMM."""
+    def _hm(self, planes):
+        """head_major argument of the projection GEMMs: [rows][D] planes per head, the Q planes carrying
+        scale * log2(e) (attention(..., q_prescaled=True))."""
+        return (self.dim_head, planes, self.scale * 1.4426950408889634)
+
+    def project_qkv(self, x2d, norm=None, head_major=False):
+        """One GEMM for Q, K, V of a self-attention style layer -> (rows, 3*inner), or with head_major
+        (3*heads, rows, dim_head).  With `norm`, x2d is the un-normalised input and the LayerNorm is
+        folded into the GEMM."""
+        hm = self._hm(self.heads) if head_major else None
         if norm is not None:
             if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim, x2d):
-                return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")))
+                return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")), head_major=hm)
             mods = (self.to_q, self.to_k, self.to_v)
             w, ln = fold_layernorm(self.__dict__, "_pk_ln_qkv", norm, [m.weight for m in mods], [m.bias for m in mods])
-            return O.gemm(x2d, w, None, ln=ln)
-        return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")))
+            return O.gemm(x2d, w, None, ln=ln, head_major=hm)
+        return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")), head_major=hm)
 
     def project_kv(self, ctx2d):
         """K and V of the context in one GEMM -> (rows_ctx, 2*inner)."""
         return O.gemm(ctx2d, self._fused(("to_k", "to_v")))
 
     def run_self(self, x2d, batch, lq, res=None, norm=None, ln_stats=False):
-        c = self.inner_dim
-        qkv = self.project_qkv(x2d, norm)
-        o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, lq, lq, self.heads,
-                        self.dim_head, self.scale)
+        c, hd = self.inner_dim, self.heads
+        if HEAD_MAJOR and self.to_q.bias is None:
+            # Q | K | V written as one contiguous [rows][D] plane per head by the projection's epilogue: the
+            # attention kernel then streams a head's K/V linearly, and Q arrives in log2 units
+            qkv = self.project_qkv(x2d, norm, head_major=True)
+            o = O.attention(qkv[:hd], qkv[hd:2 * hd], qkv[2 * hd:], batch, lq, lq, hd, self.dim_head,
+                            q_prescaled=True)
+        else:
+            qkv = self.project_qkv(x2d, norm)
+            o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, lq, lq, hd,
+                            self.dim_head, self.scale)
         return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
 
     def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None, ln_stats=False):
         c = self.inner_dim
-        q = self.to_q.run(x2d) if norm is None else self.to_q.run_ln(x2d, norm)
+        pre = HEAD_MAJOR and self.to_q.bias is None
+        kw = {"head_major": self._hm(self.heads)} if pre else {}
+        q = self.to_q.run(x2d, **kw) if norm is None else self.to_q.run_ln(x2d, norm, **kw)
         pre = self.__dict__.pop("_kv_prefetched", None)
         if kv is None and pre is not None and pre[0] is ctx2d:
             kv, side = pre[1], pre[2]                # projected ahead of time (bank GEMM, or a side stream)
@@ -394,7 +415,8 @@ class Attention(_Cached):
                     kv.record_stream(torch.cuda.current_stream())
         if kv is None:
             kv = self.project_kv(ctx2d)
-        o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale)
+        o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale,
+                        q_prescaled=pre)
         return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):

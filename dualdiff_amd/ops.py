@@ -46,6 +46,11 @@ class KernelTimer:
         self.overhead_ms = 0.5 * d[len(d) // 2]
         return self.overhead_ms
 
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
     def stop(self, e0, name, flops, nbytes):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(torch.cuda.current_stream())
@@ -245,8 +250,11 @@ def _rows2d(t):
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
          out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
-         ln_stats=False):
+         ln_stats=False, head_major=None):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
+    head_major = (D, scaled_planes, scale): the result comes back as (n / D, rows, D) — one contiguous
+    [rows][D] plane per head of a fused Q|K|V projection, the first `scaled_planes` planes multiplied by
+    `scale` before rounding (what `attention(..., q_prescaled=True)` expects).
     out_f32: the result is stored as fp32 (attention logits that feed a softmax).
     ln_stats: the epilogue also leaves per-row partial sums of the output (n % 32 == 0) as `out._ln_stats`;
     a later gemm(out, ..., ln=...) picks them up instead of recomputing the row statistics.
@@ -265,12 +273,21 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         raise ValueError("weight must be contiguous [N, K=%d], got %s" % (k, tuple(w.shape)))
     n = n_w // 2 if epilogue == DD_EPI_GEGLU else n_w
     odt = torch.float32 if out_f32 else a.dtype
+    hm_out = None
+    if head_major is not None:
+        hd, hplanes, hscale = head_major
+        if out is not None or n % hd or hd % 8 or out_f32 or epilogue != DD_EPI_NONE or accumulate or ln_stats:
+            raise ValueError("head_major needs a plain epilogue, its own output and n % D == 0")
+        hm_out = torch.empty((n // hd, rows, hd), dtype=a.dtype, device=a.device)
+        out = hm_out.view(rows, n)           # same bytes; the kernel ignores ldc in this mode
     if out is None:
         out = torch.empty((rows, n), dtype=odt, device=a.device)
     elif out.dtype != odt:
         raise TypeError("gemm: out must be %s" % odt)
     d = GemmDesc()
     d.out_f32 = int(bool(out_f32))
+    if hm_out is not None:
+        d.out_headmajor_d, d.hm_scaled_planes, d.hm_scale = int(hd), int(hplanes), float(hscale)
     d.a = a.data_ptr(); d.lda = a.stride(0); d.k1 = a.shape[1]
     if a2 is not None:
         a2 = _rows2d(a2)
@@ -310,7 +327,8 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     if tile == 0 and split_k == 0:
         d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
                                       + (("f32",) if out_f32 else ()) + (("so",) if ln_stats else ())
-                                      + (("si",) if stats_in is not None else ()),
+                                      + (("si",) if stats_in is not None else ())
+                                      + (("hm", head_major[0]) if head_major is not None else ()),
                                       (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
@@ -326,7 +344,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
     if stats_out is not None:
         out._ln_stats = stats_out
-    return out
+    return hm_out if hm_out is not None else out
 
 
 def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res=None,
@@ -421,24 +439,35 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 
 def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_map=None,
-              out=None, accumulate=False, variant=0):
+              out=None, accumulate=False, variant=0, q_prescaled=False):
     """softmax(scale * q k^T) v per (batch, head).
+
+    q / k / v may also be HEAD-MAJOR 3-D tensors (heads, rows, head_dim) — slices of a
+    `gemm(..., head_major=...)` result; q_prescaled: q already carries scale * log2(e).
 
     q: (batch*lq, >= heads*head_dim) row-strided view; k, v: (kv_batches*lk, ...) likewise, so
     slices of a fused QKV projection can be passed without copies.  kv_batch_map (int32 device
     tensor [batch]) redirects batch b to K/V of another batch (neighbour views)."""
     lib = _native.load()
     _need_gpu(q, k, v, out, kv_batch_map)
-    q, k, v = _rows2d(q), _rows2d(k), _rows2d(v)
+    d = AttnDesc()
+
+    def operand(t, l):
+        """-> (ptr, ld, batch stride, head stride) for a row-major 2-D view or a head-major 3-D tensor."""
+        if t.dim() == 3:
+            if t.shape[0] != heads or t.shape[2] != head_dim or t.stride(2) != 1 or t.stride(1) != head_dim:
+                raise ValueError("head-major operand must be (heads, rows, head_dim) with contiguous planes")
+            return t.data_ptr(), head_dim, l * head_dim, t.stride(0)
+        t = _rows2d(t)
+        return t.data_ptr(), t.stride(0), l * t.stride(0), 0
+    d.q, d.ldq, d.q_batch_stride, d.q_head_stride = operand(q, lq)
+    d.k, d.ldk, d.k_batch_stride, d.k_head_stride = operand(k, lk)
+    d.v, d.ldv, d.v_batch_stride, d.v_head_stride = operand(v, lk)
+    d.q_prescaled = int(bool(q_prescaled))
     if out is None:
         out = torch.empty((batch * lq, heads * head_dim), dtype=q.dtype, device=q.device)
     out = _rows2d(out)
-    d = AttnDesc()
-    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
-    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
-    d.q_batch_stride = lq * q.stride(0)
-    d.k_batch_stride = lk * k.stride(0)
-    d.v_batch_stride = lk * v.stride(0)
+    d.o, d.ldo = out.data_ptr(), out.stride(0)
     d.o_batch_stride = lq * out.stride(0)
     d.batch, d.heads, d.head_dim, d.lq, d.lk = batch, heads, head_dim, lq, lk
     d.scale = float(scale) if scale is not None else head_dim ** -0.5

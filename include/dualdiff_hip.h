@@ -130,6 +130,16 @@ typedef struct dd_gemm_desc {
    *   tensor ([rows][k / 32][2]) instead of a pass over the rows in every column tile's prologue. */
   void* ln_stats_out;
   const void* ln_stats_in;
+  /* Head-major output (dense mode, plain epilogue, no split-K): with out_headmajor_d = D > 0 (D % 8 == 0,
+   * n % D == 0) output column c of row r is stored at  out[((c / D) * rows + r) * D + c % D]  — one
+   * contiguous [rows][D] plane per head of a fused Q|K|V projection, so that the attention kernel streams
+   * a head's K/V rows as one linear range instead of D-element pieces of every fused row
+   * (attn1 / attn4 of blocks.py:150-236).  The first `hm_scaled_planes` planes (the Q heads) are
+   * multiplied by `hm_scale` in fp32 before the store rounding (softmax scale * log2 e, see
+   * dd_attn_desc.q_prescaled).  ldc is ignored. */
+  int32_t out_headmajor_d;
+  int32_t hm_scaled_planes;
+  float hm_scale;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
@@ -185,6 +195,11 @@ typedef struct dd_attn_desc {
   int32_t accumulate;                 /* 1: O += result */
   int32_t dtype;
   int32_t variant;                    /* 0 = default (tr-read V), 1 = plain LDS reads */
+  /* head h of q / k / v starts at element h * {q,k,v}_head_stride of its batch (0 = head_dim: the heads
+   * are column blocks of one row, the reference's layout).  A head-major projection (dd_gemm_desc.
+   * out_headmajor_d) passes ld = head_dim, batch stride = l * head_dim, head stride = rows * head_dim. */
+  int64_t q_head_stride, k_head_stride, v_head_stride;
+  int32_t q_prescaled;                /* 1: q already carries scale * log2(e); `scale` is ignored */
 } dd_attn_desc;
 
 int dd_attention(const dd_attn_desc* d, dd_stream_t stream);

@@ -485,6 +485,68 @@ def test_attention_v5_fused_qkv_and_neighbours(ops, dtype, variant):
     check(out, ref, dtype, "attn4 neighbour sum v%d" % variant, 6.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(6, 350, 8, 40), (3, 1400, 8, 40), (4, 91, 8, 160), (2, 350, 8, 80)])
+def test_attention_head_major_qkv(ops, dtype, case):
+    """Fused QKV projection written HEAD-MAJOR by the GEMM epilogue (one [rows][D] plane per head, the Q
+    planes pre-multiplied by scale * log2 e) -> attention on those planes, incl. the neighbour-view pattern
+    (kv_batch_map + accumulate).  Against the row-major reference: projection, then two attentions summed."""
+    b, l, h, d = case
+    c = h * d
+    x = rnd((b * l, c), dtype, 1)
+    w = rnd((3 * c, c), dtype, 2, c ** -0.5)
+    scale = d ** -0.5
+    qkv_hm = ops.gemm(x, w, None, head_major=(d, h, scale * 1.4426950408889634))
+    assert qkv_hm.shape == (3 * h, b * l, d)
+    qkv = ops.gemm(x, w, None)                                   # row-major twin
+    # the planes hold the same projection (Q planes scaled)
+    hm = qkv_hm.float().cpu().permute(1, 0, 2).reshape(b * l, 3 * c)
+    rm = qkv.float().cpu()
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    assert (hm[:, c:] - rm[:, c:]).abs().max().item() == 0.0
+    assert (hm[:, :c] - rm[:, :c] * scale * 1.4426950408889634).abs().max().item() <= tol * rm.abs().max().item()
+    q, k, v = qkv_hm[:h], qkv_hm[h:2 * h], qkv_hm[2 * h:]
+    left = torch.tensor([(i - 1) % b for i in range(b)], dtype=torch.int32, device="cuda")
+    right = torch.tensor([(i + 1) % b for i in range(b)], dtype=torch.int32, device="cuda")
+    out = ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left, q_prescaled=True)
+    ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=right, out=out, accumulate=True, q_prescaled=True)
+    ref = (L.attention_ref(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, l, l, h, d, kv_batch_map=left)
+           + L.attention_ref(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, l, l, h, d, kv_batch_map=right))
+    check(out, ref, dtype, "head-major attn4 %s" % (case,), 6.0)
+    own = ops.attention(q, k, v, b, l, l, h, d, q_prescaled=True)
+    check(own, L.attention_ref(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, l, l, h, d), dtype,
+          "head-major self %s" % (case,), 4.0)
+
+
+LN2 = 0.6931471805599453
+
+
+@pytest.mark.parametrize("variant", [0, 5, 7, 8, 11, 12])
+@pytest.mark.parametrize("kind", ["spike", "negative", "plain"])
+@pytest.mark.parametrize("lk", [1, 33, 200, 300])
+def test_attention_prescaled_q(ops, variant, kind, lk):
+    """q_prescaled: q carries scale * log2(e), the running max rides in the QK^T MFMA's C operand.  Late
+    spikes (rescale branch, also inside the ragged last chunk), rows whose every score is far below zero
+    (the first chunk must LOWER the initial max of 0; padded keys score above every real one), plain data."""
+    b, lq, h, d = 2, 80, 8, 40
+    dtype = torch.bfloat16
+    q = rnd((b * lq, h * d), dtype, 1)
+    k = rnd((b * lk, h * d), dtype, 2)
+    v = rnd((b * lk, h * d), dtype, 3)
+    if kind == "spike":
+        k[lk - 1] = q[7] * 6.0
+        if lk > 40:
+            k[lk // 2] = q[9] * 4.0
+    elif kind == "negative":
+        q = q + 1.5
+        k = -(k.abs() + 1.0) * 3.0
+    # q is what the projection epilogue would have stored: already in log2 units
+    y = ops.attention(q, k, v, b, lq, lk, h, d, variant=variant, q_prescaled=True)
+    ref = L.attention_ref(q, k, v, b, lq, lk, h, d, scale=LN2)
+    assert torch.isfinite(y.float()).all()
+    check(y, ref, dtype, "prescaled attention %s lk=%d v%d" % (kind, lk, variant), 4.0)
+
+
 @pytest.mark.parametrize("variant", [5, 6, 7, 8])
 def test_attention_v5_softmax_spike(ops, variant):
     b, lq, lk, h, d = 1, 64, 300, 8, 40

@@ -25,3 +25,15 @@ if __name__ == "__main__":
             except Exception as e:
                 res.append("v%d n/a" % var)
         print((b, lq, lk, h, d), " | ".join(res))
+
+    # head-major K/V (and Q) planes from the projection epilogue vs the fused row-major projection
+    for (b, l, h, d) in ((12, 1400, 8, 40), (6, 1400, 8, 40), (12, 350, 8, 80)):
+        c = h * d
+        x = torch.randn(b * l, c, device="cuda").to(dt); w = (torch.randn(3 * c, c, device="cuda") * c ** -0.5).to(dt)
+        qkv = O.gemm(x, w, None); hm = O.gemm(x, w, None, head_major=(d, h, d ** -0.5 * 1.4426950408889634))
+        out = torch.empty(b * l, c, device="cuda", dtype=dt)
+        t_rm = graph_time(lambda: O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, l, l, h, d, out=out))
+        t_hm = graph_time(lambda: O.attention(hm[:h], hm[h:2 * h], hm[2 * h:], b, l, l, h, d, out=out, q_prescaled=True))
+        g_rm = graph_time(lambda: O.gemm(x, w, None, out=qkv))
+        g_hm = graph_time(lambda: O.gemm(x, w, None, head_major=(d, h, 1.0)))
+        print((b, l, h, d), "attention row-major %.1f us | head-major %.1f us ; QKV gemm row-major %.1f | head-major %.1f" % (t_rm, t_hm, g_rm, g_hm))
