@@ -76,7 +76,7 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             self._maps[key] = maps
         return self._maps[key]
 
-    def run(self, h, batch, l, ctx2d, lc):
+    def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
         h = self._attn(self.attn1, self.norm1, h, batch, l)
         h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
         # ---- neighbour-view attention ------------------------------------------------------
@@ -101,4 +101,6 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
             h = self.connector.run(y, res=h, ln_stats=want_ln_stats())
         # ---- feed-forward ------------------------------------------------------------------
+        if defer_ff_out:
+            return self.ff.run(h, norm=self.norm3, defer_out=True), h
         return self.ff.run(h, res=h, norm=self.norm3)

@@ -460,11 +460,15 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), _Dropout(), Linear(dim * mult, dim)])
 
-    def run(self, x2d, res=None, norm=None):
+    def run(self, x2d, res=None, norm=None, defer_out=False):
+        """defer_out: return the gated hidden (rows, 4C) instead of net[2](hidden) + res — the caller folds
+        the output projection into the layer that follows (Transformer2DModel.run)."""
         if norm is None:
             g = self.net[0].proj.run(x2d, epilogue=O.DD_EPI_GEGLU)
         else:
             g = self.net[0].proj.run_ln(x2d, norm, epilogue=O.DD_EPI_GEGLU)
+        if defer_out:
+            return g
         return self.net[2].run(g, res=res)
 
 
@@ -494,9 +498,11 @@ class BasicTransformerBlock(nn.Module):
         out = attn(norm.run(h).reshape(batch, l, -1), encoder_hidden_states=e)
         return O.add(out.reshape(batch * l, -1).contiguous(), h)
 
-    def run(self, h, batch, l, ctx2d, lc):
+    def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
         h = self._attn(self.attn1, self.norm1, h, batch, l)
         h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
+        if defer_ff_out:                   # -> (gated hidden, residual): see Transformer2DModel.run
+            return self.ff.run(h, norm=self.norm3, defer_out=True), h
         return self.ff.run(h, res=h, norm=self.norm3)
 
 
@@ -514,10 +520,35 @@ class Transformer2DModel(nn.Module):
                       **(block_kwargs or {}))])
         self.proj_out = Linear(inner, in_channels, conv=True)
 
+    # The block ends with  t = W2 g + b2 + h  (feed-forward output projection + residual) and proj_out is
+    # another Linear right behind it with nothing in between (diffusers Transformer2DModel.forward; reference
+    # blocks.py:224-236): y = Wp t + bp + x = [Wp W2 | Wp] [g | h] + (Wp b2 + bp) + x — ONE GEMM over the
+    # two-source operand [g | h] (K = 5C) instead of two GEMMs and a round trip of t through HBM.  Folded in
+    # fp32 when the weights change, like the attn4 connector.  DD_FOLD_PROJ_OUT=0 turns it off.
+    fold_proj_out = __import__("os").environ.get("DD_FOLD_PROJ_OUT", "1") != "0"
+
+    def _folded_ff_out(self, blk):
+        w2, b2 = blk.ff.net[2].weight, blk.ff.net[2].bias
+        wp, bp = self.proj_out.weight, self.proj_out.bias
+        key = (w2._version, b2._version, wp._version, bp._version, w2.data_ptr(), wp.data_ptr())
+        hit = self.proj_out.__dict__.get("_pk_fold")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                wpf = wp.detach().float().reshape(wp.shape[0], -1)
+                w = torch.cat([wpf @ w2.detach().float(), wpf], dim=1).to(wp.dtype).contiguous()
+                b = (wpf @ b2.detach().float() + bp.detach().float()).to(wp.dtype).contiguous()
+            hit = self.proj_out.__dict__["_pk_fold"] = (key, w, b)
+        return hit[1], hit[2]
+
     def run(self, x, m, h, w, ctx2d, lc):
         a = self.norm.run(x, m, h * w, False)
         t = self.proj_in.run(a, ln_stats=want_ln_stats())
-        for blk in self.transformer_blocks:
+        blocks = self.transformer_blocks
+        if self.fold_proj_out and len(blocks) == 1 and isinstance(getattr(blocks[0], "ff", None), FeedForward):
+            g, hres = blocks[0].run(t, m, h * w, ctx2d, lc, defer_ff_out=True)
+            wf, bf = self._folded_ff_out(blocks[0])
+            return O.gemm(g, wf, bf, a2=hres, res=x)
+        for blk in blocks:
             t = blk.run(t, m, h * w, ctx2d, lc)
         return self.proj_out.run(t, res=x)
 
