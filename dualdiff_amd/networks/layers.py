@@ -403,8 +403,8 @@ class Attention(_Cached):
 
     def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None, ln_stats=False):
         c = self.inner_dim
-        pre = HEAD_MAJOR and self.to_q.bias is None
-        kw = {"head_major": self._hm(self.heads)} if pre else {}
+        q_hm = HEAD_MAJOR and self.to_q.bias is None
+        kw = {"head_major": self._hm(self.heads)} if q_hm else {}
         q = self.to_q.run(x2d, **kw) if norm is None else self.to_q.run_ln(x2d, norm, **kw)
         pre = self.__dict__.pop("_kv_prefetched", None)
         if kv is None and pre is not None and pre[0] is ctx2d:
@@ -416,7 +416,7 @@ class Attention(_Cached):
         if kv is None:
             kv = self.project_kv(ctx2d)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale,
-                        q_prescaled=pre)
+                        q_prescaled=q_hm)
         return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):

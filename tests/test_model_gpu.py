@@ -415,3 +415,25 @@ def test_unipc_denoiser_graph_equals_eager_and_restated_scheduler(unet_case, cne
     rec = []
     err = report("unipc latents after %d steps" % run, outs[True].reshape(NCAM, 4, H, W), x.float(), dtype, rec)
     assert err <= 1.0, rec
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_multiview_block_standalone(gpu, dtype):
+    """One BasicMultiviewTransformerBlock driven directly (no UNet around it: no cross-attention K/V bank,
+    no proj_out fold) at the L1 shape — the configuration `__graft_entry__.smoke()` runs."""
+    from dualdiff_amd.networks.blocks import BasicMultiviewTransformerBlock
+    ora = R.BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR).eval()
+    sd = {k: bf16_round(v) for k, v in seeded_state_dict(ora, 5).items()}
+    ora.load_state_dict(sd)
+    x = bf16_round(seeded_tensor((6, 350, 640), 1))
+    ctx = bf16_round(seeded_tensor((6, 30, 768), 2))
+    with torch.no_grad():
+        ref = ora(x, encoder_hidden_states=ctx)
+        with storage_emulation(ora, dtype):
+            emul = ora(x, encoder_hidden_states=ctx)
+        blk = BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR)
+        blk.load_state_dict(sd)
+        blk = blk.to("cuda", dtype)
+        y = blk.run(x.cuda().to(dtype).reshape(-1, 640), 6, 350, ctx.cuda().to(dtype).reshape(-1, 768), 30)
+    rec = []
+    assert report("multiview block standalone", y.reshape(6, 350, 640), ref, dtype, rec, emul) <= 1.0, rec
