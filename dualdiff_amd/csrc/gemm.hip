@@ -1129,6 +1129,8 @@ constexpr TileCfg kTiles[] = {
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
     {33, 2, 2, 6, 2, -1, "conv3s 192x64/w8"},
     {34, 2, 2, 6, 2, -1, "conv3s 192x64/w4"},
+    {35, 2, 2, 4, 2, -1, "conv3s 128x64/w3"},     // 72 KB of LDS: two workgroups per CU
+    {36, 2, 2, 4, 4, -1, "conv3s 128x128/w3"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1295,6 +1297,8 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
     case 33: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 8>(p, pl, s); break;
     case 34: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 4>(p, pl, s); break;
+    case 35: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 3>(p, pl, s); break;
+    case 36: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 4, 3>(p, pl, s); break;
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
     case 14: return launch_cfg2<T, 2, 2, 2, 4, 3, CONV, GEGLU>(p, pl, s);
@@ -1416,7 +1420,7 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   const TileCfg& t = kTiles[pl.tile_idx];
   if (t.stages < 0) {
     snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
-             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : 4), pl.split, pl.tiles_m, pl.tiles_n, t.name);
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 35 ? 3 : 4)), pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
