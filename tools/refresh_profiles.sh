@@ -26,6 +26,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
     --tune-cache $T > /dev/null 2>&1
 done
 python3 $R/tools/pmc_summary.py /tmp/${TAG}_FETCH_SIZE /tmp/${TAG}_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_traffic.csv
+# 3b. MFMA-pipe and VALU-issue utilisation per kernel (one more counter pass, same eager command)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU \
+  --output-format csv -d /tmp/${TAG}_MFMA -o p -- \
+  python3 $R/bench.py --steps 2 --warmup 1 --no-graph --serial-branches --no-cpu-baseline --no-roofline \
+  --tune-cache $T > /dev/null 2>&1
+python3 $R/tools/pmc_mfma_summary.py /tmp/${TAG}_MFMA $OUT/${TAG}_pmc_mfma.csv
 # 4. per-shape table of one eager step
 DD_TUNE_CACHE=$T python3 $R/tools/step_shapes.py > $OUT/${TAG}_step_shapes.txt 2>&1
 cat $OUT/${TAG}_bench.json
