@@ -864,9 +864,13 @@ void dd_gemm2_kernel(const GemmParams p) {
 // Staged bytes drop ~5x; the weight matrix is streamed once per row tile through a 3-slot ring.
 // Requirements (host-checked): stride 1, no resize, Cin % 64 == 0.  Split-K is over channel chunks.
 // =============================================================================================
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW>
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW, int GRP = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 void dd_conv3s_kernel(const GemmParams p) {
+  // GRP = 3: the weight ring is two GROUPS of three taps; a workgroup synchronises (DMA wait + barrier)
+  // once per group instead of once per tap — 72 MFMAs per wave between barriers instead of 24 — and the
+  // next group's three weight tiles are in flight under them.
+  static_assert(GRP == 1 || (GRP == 3 && NSW == 6), "grouped taps: 2 groups of 3 slots");
   using V8 = typename dd_vec<T>::v8;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 16;
@@ -949,6 +953,9 @@ void dd_conv3s_kernel(const GemmParams p) {
           const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
           if (rv && iy >= 0 && iy < p.hout && ix >= 0 && ix < p.wout) ra = (uint32_t)(g * hw + iy * p.wout + ix);
         }
+        // the entry is the fragment's LDS address in 16-byte units: row * 8 + swizzled chunk of k-step 0
+        // (k-step 1 is the same address with bit 2 of the chunk flipped); AROWS * 8 + 7 < 2^16
+        ra = ra * 8u + ((uint32_t)(lane >> 4) ^ ((ra >> 1) & 7u));
         packed |= ra << (16 * h);
       }
       tab[tm][t2] = packed;
@@ -983,7 +990,7 @@ void dd_conv3s_kernel(const GemmParams p) {
   if (nc > 0) {
     issue_a(0);
 #pragma unroll
-    for (int s0 = 0; s0 < NSW - 1; ++s0)
+    for (int s0 = 0; s0 < (GRP == 1 ? NSW - 1 : NSW); ++s0)
       if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0);
   }
   int wslot = 0;                                        // ring slot of step s (scalar)
@@ -999,10 +1006,8 @@ void dd_conv3s_kernel(const GemmParams p) {
     for (int j = 0; j < TM; ++j) {
       uint32_t ra = (tab[j][t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
       asm volatile("" : "+v"(ra));       // keep the 54 gather addresses out of registers: recompute per step
-      const uint32_t c0 = (uint32_t)fchunk ^ ((ra >> 1) & 7u);
-      const T* src = ab + ra * BK;
-      xf[par][0][j] = dd_as_v8<T>(dd_ld16(src + (c0 << 3)));
-      xf[par][1][j] = dd_as_v8<T>(dd_ld16(src + ((c0 ^ 4u) << 3)));
+      xf[par][0][j] = dd_as_v8<T>(dd_ld16(ab + (ra << 3)));
+      xf[par][1][j] = dd_as_v8<T>(dd_ld16(ab + ((ra ^ 4u) << 3)));
     }
   };
   auto step = [&](const int c, auto tap_c, auto par_c) __attribute__((always_inline)) {
@@ -1010,6 +1015,7 @@ void dd_conv3s_kernel(const GemmParams p) {
     constexpr int par = decltype(par_c)::value;
     const bool more_c = c + 1 < nc;
     const int s = c * 9 + t;
+    if constexpr (GRP == 1) {
     // W(s) (and with it, in issue order, A(c)) must have landed.  Younger loads that may stay in
     // flight: W(s+1..s+NSW-2), and A(c+1) when it was issued after W(s) (1 <= t <= NSW-2).  The
     // last NSW-2 steps simply drain.
@@ -1026,6 +1032,21 @@ void dd_conv3s_kernel(const GemmParams p) {
       if (slot >= NSW) slot -= NSW;
       constexpr int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;
       issue_w(c + ca, ta, slot);
+    }
+    } else if constexpr (t % GRP == 0) {
+      // group start: this group's taps (issued one group ago; the first two groups in the prologue) must
+      // have landed; only at the very first group may the second group still be in flight
+      if (s == 0 && GRP < nsteps) wait_vmcnt<GRP * WI>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();              // everyone is done with the previous group's slots
+      if (t == 0 && more_c) issue_a(c + 1);
+      if (s >= GRP && s + GRP < nsteps) {        // next group into the slots just freed
+        int slot = wslot + GRP;
+        if (slot >= NSW) slot -= NSW;
+        constexpr int t1 = (t + GRP) % 9, c1 = (t + GRP) / 9;
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) issue_w(c + c1, t1 + u, slot + u);
+      }
     }
     const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
     if (++wslot == NSW) wslot = 0;
@@ -1131,6 +1152,8 @@ constexpr TileCfg kTiles[] = {
     {34, 2, 2, 6, 2, -1, "conv3s 192x64/w4"},
     {35, 2, 2, 4, 2, -1, "conv3s 128x64/w3"},     // 72 KB of LDS: two workgroups per CU
     {36, 2, 2, 4, 4, -1, "conv3s 128x128/w3"},
+    {37, 2, 2, 6, 2, -1, "conv3s 192x64/g3"},     // taps in groups of three: one barrier per 72 MFMAs
+    {38, 2, 2, 4, 2, -1, "conv3s 128x64/g3"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1274,12 +1297,12 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NSW>
+template <typename T, int WM, int WN, int TM, int TN, int NSW, int GRP = 1>
 int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr size_t smem = (size_t)(2 * (BM + 64) + NSW * BN) * BK * sizeof(T);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = dd_conv3s_kernel<T, WM, WN, TM, TN, NSW>;
+  auto kern = dd_conv3s_kernel<T, WM, WN, TM, TN, NSW, GRP>;
   static bool attr_set = false;
   if (!attr_set && smem > 65536) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1299,6 +1322,8 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 34: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 4>(p, pl, s); break;
     case 35: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 3>(p, pl, s); break;
     case 36: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 4, 3>(p, pl, s); break;
+    case 37: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 6, 3>(p, pl, s); break;
+    case 38: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 6, 3>(p, pl, s); break;
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
     case 14: return launch_cfg2<T, 2, 2, 2, 4, 3, CONV, GEGLU>(p, pl, s);
@@ -1420,7 +1445,7 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   const TileCfg& t = kTiles[pl.tile_idx];
   if (t.stages < 0) {
     snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
-             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 35 ? 3 : 4)), pl.split, pl.tiles_m, pl.tiles_n, t.name);
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4))), pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol

@@ -157,7 +157,7 @@ def test_conv3x3_dma_tiles(ops, tile, case):
         check(y, ref, dtype, "conv dma tile%d split%d %s" % (tile, split, case))
 
 
-CONV3S_TILES = [31, 33, 34, 35, 36]
+CONV3S_TILES = [31, 33, 34, 35, 36, 37, 38]
 # (m, h, w, cin, cout): 4x7 / 7x13 / 14x25 levels, ragged instance counts (partial last tile), one
 # instance per tile, Cout not a multiple of the tile
 CONV3S_CASES = [(12, 4, 7, 1280, 1280), (5, 4, 7, 128, 192), (12, 7, 13, 640, 1280), (7, 7, 13, 192, 64),
@@ -171,7 +171,7 @@ def test_conv3x3_small_image_direct(ops, tile, case, dtype):
     """Direct small-image conv family (dd_conv3s_kernel): whole instances per workgroup, taps as LDS
     row gathers; with the ResnetBlock2D epilogue and split-K over channel chunks."""
     m, h, w_, cin, cout = case
-    if h * w_ > {31: 384, 35: 128, 36: 128}.get(tile, 192):
+    if h * w_ > {31: 384, 35: 128, 36: 128, 38: 128}.get(tile, 192):
         pytest.skip("image larger than the tile")
     x = rnd((m * h * w_, cin), dtype, 1)
     w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)

@@ -15,7 +15,7 @@ def cold(fn, warm, n=5):
 for (cin, cout, h, w) in ((1280, 1280, 4, 7), (2560, 1280, 4, 7), (1280, 1280, 7, 13), (2560, 1280, 7, 13), (1920, 1280, 7, 13)):
     x, wt, b = r(M * h * w, cin), r(cout, 9 * cin, s=0.02), r(cout)
     res = []
-    for tile in (31, 33, 34, 35, 36, 13, 17, 20, 11):
+    for tile in (31, 33, 34, 35, 36, 37, 38, 13, 17, 20, 11):
         for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
             try:
                 t = cold(lambda: O.conv3x3(x, wt, b, M, h, w, tile=tile, split_k=sp), (x,))
