@@ -697,3 +697,29 @@ def test_ors_projection_rejects_bad_input():
     with pytest.raises(TypeError):
         O.ors_project(occ, torch.zeros(1, 3, device="cuda"), torch.zeros(1, 4, 3, device="cuda"), 8,
                       cond_dtype=torch.float32)
+
+
+def test_ors_projection_edge_cases():
+    """Rays that never enter the volume (camera far outside, looking away) give class 17 everywhere; an
+    empty volume (all 17) gives 17 everywhere; a camera inside a uniform volume reads that class until its
+    rays leave the 80 m x 80 m x 6.4 m box, and 17 after."""
+    from oracle import ors_projection as P
+    from dualdiff_amd.networks.occ3d_proj import OccupancyRay
+    K = torch.tensor([[1260.0, 0.0, 800.0], [0.0, 1260.0, 450.0], [0.0, 0.0, 1.0]])
+    proj = OccupancyRay(image_shape=(900, 1600), sample_point=64, sample_step=0.5, compress_ratio=16 / 1600,
+                        device="cuda")
+    h, w = proj.image_shape_compress
+    # camera axes: z forward = +x of the ego frame, x right = -y, y down = -z
+    R = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    away = torch.eye(4); away[:3, :3] = R; away[:3, 3] = torch.tensor([100.0, 0.0, 1.0])       # 60 m outside, looking out
+    inside = torch.eye(4); inside[:3, :3] = R; inside[:3, 3] = torch.tensor([0.0, 0.0, 1.0])
+    full = torch.full((200, 200, 16), 5)
+    lab = proj.project_volume(full, [K, K], [away, inside]).cpu()
+    assert torch.equal(lab, P.ors_project(full, [K, K], [away, inside], h, w, 16 / 1600, 64, 0.5))
+    assert (lab[0] == 17).all()
+    assert (lab[1, :, :, 0] == 5).all() and (lab[1, h // 2, w // 2, :60] == 5).all()
+    assert (lab[1] == 17).any()                               # steep rays leave through the top / bottom
+    empty = torch.full((200, 200, 16), 17)
+    assert (proj.project_volume(empty, [K], [inside]) == 17).all()
+    cond = proj.condition_volume(empty, [K], [inside], dtype=torch.bfloat16)
+    assert cond.shape == (1, 64, h, w) and (cond.float() == 1.0).all()
