@@ -198,7 +198,11 @@ def main():
                          "scaling); cfg-split: rank pairs share a scene, one CFG half each, and all-gather the "
                          "noise prediction every step (single-scene latency mode, needs an even --gpus)")
     ap.add_argument("--tune-cache", default=os.environ.get("DD_TUNE_CACHE"),
-                    help="load the tile/split-K table from this file if present, write it after warm-up")
+                    help="load the tile/split-K table from this file if present, write it after warm-up "
+                         "(default: the tracked dualdiff_amd/tuned/gfx950.json is loaded, nothing is written)")
+    ap.add_argument("--retune", action="store_true",
+                    help="ignore the tracked table, time every shape again and write the result to --tune-cache "
+                         "(default target: dualdiff_amd/tuned/gfx950.json, merged with its other entries)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,7 +230,10 @@ def main():
     from dualdiff_amd import ops as O
     from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
 
-    if args.tune_cache and os.path.exists(args.tune_cache):
+    if args.retune:
+        O.forget_tuned()
+        args.tune_cache = args.tune_cache or O.TUNE_TABLE_PATH
+    elif args.tune_cache and os.path.exists(args.tune_cache):
         O.load_tuned(args.tune_cache)
     unet, cns = build_models(dtype, device)
     cfg_kw = {}
@@ -262,7 +269,7 @@ def main():
         for i in range(args.warmup):
             den.step(i % 50)
         barrier()
-        if args.tune_cache and rank == 0 and not os.path.exists(args.tune_cache):
+        if args.tune_cache and rank == 0 and (args.retune or not os.path.exists(args.tune_cache)):
             O.save_tuned(args.tune_cache)
         t0 = time.perf_counter()
         for i in range(args.steps):

@@ -607,10 +607,8 @@ int launch_attn5p(const AttnParams& p, hipStream_t s) {
   pp.nqb = (p.lq + qblk - 1) / qblk;
   dim3 grid(pp.nqb * p.batch * p.heads);
   auto kern = dd_attn5_kernel<T, D, QT, KV_TILE, NBUF, WPE, PRE>;
-  if (smem > 65536) {
-    static bool once = false;       // per instantiation
-    if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); once = true; }
-  }
+  static std::atomic<uint64_t> attr_done{0};       // per instantiation, one bit per device
+  dd_ensure_dyn_lds((const void*)kern, smem, attr_done);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, pp);
   return dd_check_launch();
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/dualdiff_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -101,3 +102,16 @@ static inline int dd_check_launch() {
   return hipGetLastError() == hipSuccess ? DD_OK : DD_ERR_LAUNCH;
 }
 static inline bool dd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Kernels that need more than 64 KB of dynamic LDS must raise hipFuncAttributeMaxDynamicSharedMemorySize,
+// and that attribute is PER DEVICE: one flag bit per device ordinal (a process-wide bool would leave a
+// second GPU of the same process without it), thread-safe.
+static inline void dd_ensure_dyn_lds(const void* kern, size_t smem, std::atomic<uint64_t>& done) {
+  if (smem <= 65536) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  done.fetch_or(bit, std::memory_order_release);
+}

@@ -1270,12 +1270,8 @@ int launch_cfg(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(T);
   auto kern = dd_gemm_kernel<T, WM, WN, TM, TN, CONV, GEGLU>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
   return dd_check_launch();
@@ -1286,12 +1282,8 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
   auto kern = dd_gemm2_kernel<T, WM, WN, TM, TN, NSTAGE, CONV, GEGLU>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
   return dd_check_launch();
@@ -1303,12 +1295,8 @@ int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr size_t smem = (size_t)(2 * (BM + 64) + NSW * BN) * BK * sizeof(T);
   static_assert(smem <= 160 * 1024, "LDS");
   auto kern = dd_conv3s_kernel<T, WM, WN, TM, TN, NSW, GRP>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
   return dd_check_launch();

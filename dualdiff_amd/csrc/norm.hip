@@ -42,6 +42,15 @@ __device__ __forceinline__ const T* gn_src(const GnParams& p, int64_t row, int c
 
 constexpr int GN_UNROLL = 4;
 
+// Variance by E[(x-p)^2] - E[x-p]^2 around a per-(instance, group) PIVOT p = the group's first element
+// (pixel 0, first channel): with p within a few standard deviations of the mean the subtraction loses
+// nothing, whereas the textbook E[x^2] - mean^2 loses log2(mean^2 / var) bits — real SD checkpoints
+// have groups whose |mean| is ~100x their std.  One extra scalar load per group, no extra pass.
+template <typename T>
+__device__ __forceinline__ float gn_pivot(const GnParams& p, int inst, int g) {
+  return (float)*gn_src<T>(p, (int64_t)inst * p.hw, g * p.cpg);
+}
+
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS)
 void dd_gn_stats_kernel(const GnParams p) {
@@ -61,9 +70,13 @@ void dd_gn_stats_kernel(const GnParams p) {
     float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
     if (mp.active && cv < mp.cv_count) {
       const int ch = cv << 3;
-      float s[8], ss[8];
+      float s[8], ss[8], pv[8];
+      {
+        const int ga = ch / p.cpg, gb = min((ch + 7) / p.cpg, p.groups - 1);
+        const float pa = gn_pivot<T>(p, inst, ga), pb = gn_pivot<T>(p, inst, gb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; pv[e] = (ch + e) / p.cpg == ga ? pa : pb; }
+      }
       int px = p0 + mp.pl;
       for (; px + (GN_UNROLL - 1) * mp.pl_count < p1; px += GN_UNROLL * mp.pl_count) {
         u32x4 v[GN_UNROLL];
@@ -75,14 +88,14 @@ void dd_gn_stats_kernel(const GnParams p) {
           float f[8];
           dd_unpack8<T>(v[u], f);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+          for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; ss[e] += d * d; }
         }
       }
       for (; px < p1; px += mp.pl_count) {
         float f[8];
         dd_unpack8<T>(dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px, ch)), f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; ss[e] += d * d; }
       }
       g0 = ch / p.cpg;
       const int gl = (ch + 7) / p.cpg;
@@ -160,9 +173,9 @@ void dd_gn_apply_kernel(const GnParams p) {
       float a = 0.f, b = 0.f;
       for (int c = 0; c < nchunk; ++c) { a += s_ps[c * p.groups + threadIdx.x]; b += s_pq[c * p.groups + threadIdx.x]; }
       const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
-      const float mean = a * inv_n;
-      const float var = fmaxf(b * inv_n - mean * mean, 0.f);
-      s_mean[threadIdx.x] = mean;
+      const float dm = a * inv_n;                        // mean - pivot
+      const float var = fmaxf(b * inv_n - dm * dm, 0.f);
+      s_mean[threadIdx.x] = gn_pivot<T>(p, inst, threadIdx.x) + dm;
       s_rstd[threadIdx.x] = rsqrtf(var + p.eps);
     }
   }
@@ -242,6 +255,8 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
   // statistics in one pass (sum, sum of squares — the arithmetic of the two-launch path), reduced in
   // a fixed order (2 barriers, bit-reproducible).
   float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
+  const float piv0 = gn_pivot<T>(p, inst, blockIdx.x * gpb + g0);
+  const float piv1 = gn_pivot<T>(p, inst, blockIdx.x * gpb + g1);
 #pragma unroll
   for (int i = 0; i < NVMAX; ++i) {
     if (i < nv) {
@@ -250,7 +265,7 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
       const float keep = pl + i * plc < p.hw ? 1.f : 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float v = keep * f[e];
+        const float v = keep * (f[e] - (e < nfirst ? piv0 : piv1));
         if (e < nfirst) { a0 += v; q0 += v * v; } else { a1 += v; q1 += v * v; }
       }
     }
@@ -278,9 +293,9 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
       sum = dd_wave_sum(sum);
       sq = dd_wave_sum(sq);
       if (lane == 0) {
-        const float mean = sum * inv_n;
-        s_mean[g] = mean;
-        s_rstd[g] = rsqrtf(fmaxf(sq * inv_n - mean * mean, 0.f) + p.eps);
+        const float dm = sum * inv_n;                    // mean - pivot
+        s_mean[g] = gn_pivot<T>(p, inst, blockIdx.x * gpb + g) + dm;
+        s_rstd[g] = rsqrtf(fmaxf(sq * inv_n - dm * dm, 0.f) + p.eps);
       }
     }
   }

@@ -362,8 +362,16 @@ class Attention(_Cached):
             self.__dict__[key] = torch.cat([getattr(self, n).weight.detach() for n in names], dim=0).contiguous()
         return self.__dict__[key]
 
-    def _drop_cache(self):
-        super()._drop_cache()
+    def _fused_bias(self, names):
+        """Concatenated biases of the fused projection (None for the bias-free SD layers)."""
+        mods = [getattr(self, n) for n in names]
+        if all(m.bias is None for m in mods):
+            return None
+        key = "_pk_b_" + "".join(names)
+        if key not in self.__dict__:
+            self.__dict__[key] = torch.cat([
+                m.bias.detach() if m.bias is not None else m.weight.new_zeros(m.out_features) for m in mods]).contiguous()
+        return self.__dict__[key]
 
     def _hm(self, planes):
         """head_major argument of the projection GEMMs: [rows][D] planes per head, the Q planes carrying
@@ -377,15 +385,17 @@ class Attention(_Cached):
         hm = self._hm(self.heads) if head_major else None
         if norm is not None:
             if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim, x2d):
-                return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")), head_major=hm)
+                return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")),
+                              self._fused_bias(("to_q", "to_k", "to_v")), head_major=hm)
             mods = (self.to_q, self.to_k, self.to_v)
             w, ln = fold_layernorm(self.__dict__, "_pk_ln_qkv", norm, [m.weight for m in mods], [m.bias for m in mods])
             return O.gemm(x2d, w, None, ln=ln, head_major=hm)
-        return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")), head_major=hm)
+        return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")), self._fused_bias(("to_q", "to_k", "to_v")),
+                      head_major=hm)
 
     def project_kv(self, ctx2d):
         """K and V of the context in one GEMM -> (rows_ctx, 2*inner)."""
-        return O.gemm(ctx2d, self._fused(("to_k", "to_v")))
+        return O.gemm(ctx2d, self._fused(("to_k", "to_v")), self._fused_bias(("to_k", "to_v")))
 
     def run_self(self, x2d, batch, lq, res=None, norm=None, ln_stats=False):
         c, hd = self.inner_dim, self.heads
@@ -707,7 +717,7 @@ class CrossKVBank:
 
     def run(self, ctx2d):
         mods = [m for m in self.layers if isinstance(m.processor, HIPAttnProcessor)
-                and m.to_k.in_features == ctx2d.shape[1]]
+                and m.to_k.in_features == ctx2d.shape[1] and m.to_k.bias is None and m.to_v.bias is None]
         if not mods:
             return
         key = tuple((m.to_k.weight._version, m.to_v.weight._version, m.to_k.weight.data_ptr()) for m in mods)

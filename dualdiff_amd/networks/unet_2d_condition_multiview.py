@@ -264,9 +264,17 @@ class UNet2DConditionModelMultiview(ModelBase):
         skips, temb, ctx2d, lc = list(state["skips"]), state["temb"], state["ctx2d"], state["lc"]
 
         def plus(t, r):
-            if isinstance(r, (tuple, list)):
-                return O.add(t, r[0], r[1]) if len(r) == 2 else O.add(t, r[0])
-            return O.add(t, r)
+            """t + sum(r): any number of branches (pipeline_bev_controlnet.py:421-429 sums them all),
+            two operands per 3-input add."""
+            if not isinstance(r, (tuple, list)):
+                r = (r,)
+            if len(r) == 0:
+                return t
+            i = 0
+            while i < len(r):
+                t = O.add(t, r[i], r[i + 1]) if i + 1 < len(r) else O.add(t, r[i])
+                i += 2
+            return t
 
         # ControlNet residual add on the skips (:464-473) and on the mid output (:487-488)
         if down_res is not None:

@@ -87,11 +87,20 @@ def tuned_table():
     return dict(_TUNED)
 
 
-def save_tuned(path):
-    """Persist the tuned (tile, split-K) table so a later process skips the timing sweep."""
+def save_tuned(path, merge=True):
+    """Persist the tuned (tile, split-K) table so a later process skips the timing sweep.  merge: entries of
+    an existing file that this process did not touch (other dtype, other batch) are kept."""
+    import ast
     import json
+    entries = {}
+    if merge and _os.path.exists(path):
+        with open(path) as f:
+            for k, v in json.load(f).get("entries", []):
+                entries[ast.literal_eval(k)] = (int(v[0]), int(v[1]))
+    entries.update(_TUNED)
+    _os.makedirs(_os.path.dirname(_os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
-        json.dump({"arch": "gfx950", "entries": [[repr(k), list(v)] for k, v in sorted(_TUNED.items(), key=repr)]}, f, indent=0)
+        json.dump({"arch": "gfx950", "entries": [[repr(k), list(v)] for k, v in sorted(entries.items(), key=repr)]}, f, indent=0)
 
 
 def load_tuned(path):
@@ -114,6 +123,31 @@ def load_tuned(path):
 _COLD = _os.environ.get("DD_AUTOTUNE_COLD", "1") != "0"
 _FLUSH = {}
 
+# The tuned table of the shapes the denoising step touches is TRACKED (dualdiff_amd/tuned/gfx950.json,
+# written by `bench.py --retune`) and loaded on first use, so every process launches the same kernels
+# for the same shapes and the bench's roofline line can be recomputed from profiles/.  Only shapes that
+# are not in the table are timed at run time.  DD_TUNE_TABLE=0 ignores the tracked table, DD_TUNE_TABLE=<path>
+# loads another one.
+TUNE_TABLE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned", "gfx950.json")
+_TABLE_LOADED = False
+
+
+def _load_default_table():
+    global _TABLE_LOADED
+    if _TABLE_LOADED:
+        return
+    _TABLE_LOADED = True
+    path = _os.environ.get("DD_TUNE_TABLE", TUNE_TABLE_PATH)
+    if path != "0" and _os.path.exists(path):
+        load_tuned(path)
+
+
+def forget_tuned():
+    """Drop every tuned entry (bench.py --retune) and do not read the tracked table again."""
+    global _TABLE_LOADED
+    _TUNED.clear()
+    _TABLE_LOADED = True
+
 
 def _flush_and_warm(device, warm):
     """Puts the caches in the state a launch sees inside the step: weights COLD (a step streams
@@ -129,6 +163,7 @@ def _flush_and_warm(device, warm):
 
 
 def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
+    _load_default_table()
     hit = _TUNED.get(key)
     if hit is not None:
         return hit
@@ -176,7 +211,7 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
         for split in _SPLITS:
             if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):
                 continue
-            t = timed(tile, split, 1 if _COLD else 3)
+            t = timed(tile, split, 3)            # >= 3 samples per candidate, cold or hot
             if t is not None:
                 cands.append((t, tile, split))
     # the coarse pass is noisy: re-time the front-runners with more launches
@@ -218,20 +253,32 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_WS_IN_GRAPH = set()      # keys whose current buffer a captured HIP graph holds a raw pointer to
+_WS_RETIRED = []          # such buffers after they were outgrown: kept alive for the graphs that use them
+
+
 def workspace(nbytes, device, kind="gemm"):
     """Grow-only fp32 scratch buffer per (device, stream, kind): kernels on concurrent streams must
     not share scratch, and the split-K buffer (whose leading counter region dd_gemm keeps at zero)
-    is never lent to GroupNorm.  Zero-filled on allocation; allocate before graph capture."""
+    is never lent to GroupNorm.  Zero-filled on allocation; allocate before graph capture.
+    A buffer that was handed out during a capture is never freed (torch's stream handles are pooled and
+    re-used, so a later, larger eager workload can outgrow a buffer that a live graph still writes to)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream().cuda_stream, kind)
     ws = _WS.get(key)
     need = max(int(nbytes), _WS_MIN_BYTES)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None or ws.numel() * 4 < need:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise RuntimeError("workspace would have to grow during graph capture; run one eager "
                                "warm-up step first")
+        if ws is not None and key in _WS_IN_GRAPH:
+            _WS_RETIRED.append(ws)
+            _WS_IN_GRAPH.discard(key)
         ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
+    if capturing:
+        _WS_IN_GRAPH.add(key)
     return ws
 
 

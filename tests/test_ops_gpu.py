@@ -390,6 +390,23 @@ def test_groupnorm(ops, dtype, m, hw, c1, c2, silu, eps):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,hw,c", [(2, 1400, 320), (2, 350, 640), (3, 28, 1280), (1, 5600, 128)])
+def test_groupnorm_large_mean(ops, dtype, m, hw, c):
+    """Groups whose |mean| is ~100x their std (real SD checkpoints have them): a one-pass
+    E[x^2] - mean^2 variance loses ~13 bits of the fp32 statistics there; the kernels accumulate around a
+    per-group pivot instead.  The values are exactly representable inputs, so the reference (two-pass,
+    fp32) sees the same numbers."""
+    gen = torch.Generator().manual_seed(5)
+    base = (torch.randn((m, 1, 32, 1), generator=gen) * 60.0 + 100.0).expand(m, hw, 32, c // 32)
+    x = (base + torch.randn((m, hw, 32, c // 32), generator=gen)).reshape(m * hw, c).to(dtype).cuda()
+    g = rnd((c,), dtype, 3) + 1.0
+    b = rnd((c,), dtype, 4)
+    y = ops.groupnorm(x, g, b, m, hw, 32, 1e-5, False)
+    ref = L.groupnorm_ref(x, g, b, m, hw, 32, 1e-5, False)
+    check(y, ref, dtype, "groupnorm large-mean m%d hw%d c%d" % (m, hw, c), 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,c", [(1400 * 2, 320), (701, 640), (91, 1280)])
 def test_layernorm(ops, dtype, rows, c):
     x = rnd((rows, c), dtype, 1) * 3 + 1
