@@ -9,7 +9,7 @@ One *step* = one full iteration of the sampler loop body
 (ORS panorama branch with the condition embedder + ORS-3D branch, SFA on in both) + multiview
 UNet on 2 (CFG) x 6 views = 12 view-instances of 28x50 latents + CFG combine + DDIM update.
 Workload = BASELINE.json configs[1].  Synthetic inputs, random-init weights of the real
-architecture (921 M UNet + 2 x 369 M ControlNet parameters), bf16 storage, fp32 accumulation.
+architecture (921 M UNet + 2 x 369 M ControlNet parameters), fp16 storage by default (the reference dtype; bf16 measured alongside), fp32 accumulation.
 The step-invariant conditioning is RECOMPUTED every step like the reference does (pass
 --hoist-invariant to evaluate it once per sample instead).
 
@@ -91,39 +91,88 @@ def synthetic_inputs(b, dtype, device, seed):
     return dev(lat), dev(prompt), dev(cam), [dev(boxes(NCAM)), dev(boxes(1))], [dev(c) for c in conds]
 
 
-def cpu_baseline():
-    """CPU oracle (kind 'port': restated diffusers blocks + reference-owned blocks, oracle/) timed on
-    the host cores.  Bounded sample of the same workload: ONE ORS-3D ControlNet-branch forward (SFA
-    on) on 6 view-instances in fp32 = 508 of the 5922 GFLOP of a config-2 step, scaled to steps/s by
-    that FLOP share.  Threads are capped at 32 (more oversubscribes torch's CPU kernels at this size)."""
+def _cpu_models():
+    """fp32 CPU oracle models (kind 'port': restated diffusers blocks + reference-owned blocks, oracle/) with
+    cheap deterministic weights."""
+    from oracle import diffusers_restated as D
     from oracle import dualdiff_restated as R
+
+    def fill(mod):
+        """Constant per-tensor values (memset speed; the dense CPU kernels' timing does not depend on the data):
+        +-4e-4 for matrices / conv kernels, 1 for norm scales, 0 for biases."""
+        mod = mod.to_empty(device="cpu").eval()
+        with torch.no_grad():
+            for i, (n_, t_) in enumerate(mod.state_dict().items()):
+                if t_.is_floating_point():
+                    if t_.dim() >= 2:
+                        t_.fill_(4e-4 if i % 2 else -4e-4)
+                    else:
+                        t_.fill_(1.0 if n_.endswith("weight") else 0.0)
+        return mod
+
+    with torch.device("meta"):                       # skip torch's slow default initialisers
+        plain = D.UNet2DConditionModel(cross_attention_dim=768)
+        unet = R.UNet2DConditionModelMultiview(cross_attention_dim=768, neighboring_view_pair=PAIR)
+        cns = [R.BEVControlNetModel(use_occ_3d=False), R.BEVControlNetModel(use_occ_3d=True)]
+    # one copy of each weight in memory: the plain SD-1.5 UNet aliases the multiview UNet's stock tensors
+    # and the ORS-3D branch aliases the panorama branch's (timing does not depend on the values)
+    unet, cns[0] = fill(unet), fill(cns[0])
+    plain.load_state_dict(unet.state_dict(), strict=False, assign=True)
+    cns[1].load_state_dict(cns[0].state_dict(), strict=False, assign=True)
+    for mod in (plain, cns[1]):
+        assert not any(t.is_meta for t in mod.state_dict().values())
+    return plain.eval(), unet, [c.eval() for c in cns], R
+
+
+def cpu_baseline(full_steps=1):
+    """The CPU oracle timed on the host cores, rank 0 / N = 1 only, bounded to ~25 s:
+      * config 1 (BASELINE configs[0]): one view, plain SD-v1.5 UNet, null text, one DDIM step at t = 981 —
+        one warm-up + median of 3;
+      * config 2 (the bench workload): `full_steps` COMPLETE steps (2 ControlNet branches + multiview UNet on 12
+        view-instances + CFG + DDIM, oracle.denoise_step) after a warm-up (the config-1 runs plus one
+        ControlNet-branch forward, which touch every layer shape class); `value` = 1 / median step time —
+        no FLOP-share scaling.
+    Threads are capped at 32 (more oversubscribes torch's CPU kernels at these sizes)."""
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
-    with torch.device("meta"):                       # skip torch's slow default initialisers
-        cn = R.BEVControlNetModel(use_occ_3d=True)
-    cn = cn.to_empty(device="cpu").eval()
+    plain, unet, cns, R = _cpu_models()
+    ts, ratio = R.ddim_timesteps(50)
+    acp = R.ddim_alphas()
+    coef = R.ddim_coefs(acp, int(ts[0]), ratio)
+    x1 = torch.randn((1, 4, H, W), generator=g)
+    null_txt = torch.zeros((1, LTXT, 768))
+    t1 = []
     with torch.no_grad():
-        for n_, t_ in cn.state_dict().items():
-            if t_.is_floating_point():
-                if t_.dim() >= 2:     # cheap deterministic pattern (timing does not depend on the values)
-                    t_.view(-1).copy_(((torch.arange(t_.numel()) % 97) - 48).float() * 4e-4)
-                else:
-                    t_.fill_(1.0 if n_.endswith("weight") else 0.0)
-    lat = torch.randn((1, NCAM, 4, H, W), generator=g)
-    boxes = {"bboxes": torch.randn((1, 1, NBOX, 8, 3), generator=g), "classes": torch.zeros((1, 1, NBOX), dtype=torch.long),
-             "masks": torch.ones((1, 1, NBOX), dtype=torch.bool)}
-    args = (lat, torch.tensor([500]), torch.randn((1, NCAM, 3, 7), generator=g), boxes,
-            torch.randn((1, LTXT, 768), generator=g), torch.rand((NCAM, 320, H, W), generator=g))
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        cn(*args)
-        dt = time.perf_counter() - t0
+        for _ in range(4):
+            t0 = time.perf_counter()
+            eps = plain(x1, torch.tensor(int(ts[0])), encoder_hidden_states=null_txt).sample
+            _ = coef[2] * (x1 - coef[1] * eps) / coef[0] + coef[3] * eps
+            t1.append(time.perf_counter() - t0)
+        c1 = sorted(t1[1:])[1]
+        lat = torch.randn((1, 1, 4, H, W), generator=g).expand(-1, NCAM, -1, -1, -1).contiguous()
+        prompt = torch.randn((2, LTXT, 768), generator=g)
+        cam = torch.randn((2, NCAM, 3, 7), generator=g)
+
+        def boxes(nv):
+            return {"bboxes": torch.randn((2, nv, NBOX, 8, 3), generator=g), "classes": torch.zeros((2, nv, NBOX), dtype=torch.long),
+                    "masks": torch.ones((2, nv, NBOX), dtype=torch.bool)}
+        bx = [boxes(NCAM), boxes(1)]
+        conds = [torch.rand((2, 3, 224, 2400), generator=g), torch.rand((2 * NCAM, 320, H, W), generator=g)]
+        cns[1](torch.cat([lat] * 2), torch.tensor([500, 500]), cam, bx[1], prompt, conds[1])      # warm-up
+        t2 = []
+        for _ in range(max(1, full_steps)):
+            t0 = time.perf_counter()
+            R.denoise_step(unet, cns, lat, int(ts[0]), prompt, cam, bx, conds, 2.0, coef)
+            t2.append(time.perf_counter() - t0)
+    c2 = sorted(t2)[len(t2) // 2]
     step_gf = 12 * GF_UNET + 24 * GF_CNET
-    share = 6 * GF_CNET / step_gf
-    return {"value": share / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "1 fp32 oracle ControlNet-branch forward on 6 view-instances (%.0f of %.0f GFLOP/step) "
-                      "in %.2f s on %d threads, scaled by FLOP share" % (6 * GF_CNET, step_gf, dt, cores)}
+    return {"value": 1.0 / c2, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d full config-2 step(s) of the fp32 CPU oracle (2 ControlNet branches + multiview UNet on 12 "
+                      "view-instances + CFG + DDIM; median %.2f s = %.0f GFLOP/s) on %d threads after a warm-up; "
+                      "config 1 (1 view, plain SD-1.5 UNet, null text, 1 DDIM step): median of 3 = %.3f s"
+                      % (len(t2), c2, step_gf / c2, cores, c1),
+            "config1_single_view_steps_per_s": 1.0 / c1, "config1_seconds": c1, "config2_seconds": c2}
 
 
 def _metric_name():
@@ -161,17 +210,27 @@ def _mangled_fragment(kernel):
     return out + ("E" if closed else "")
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 +
-    WRITE_SIZE, separate passes, tools/pmc_summary.py + tools/refresh_profiles.sh); None when the
-    profile has no such kernel.  Several instantiations matching the label are launch-weighted."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
+def _pmc_table():
+    """Committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes, tools/pmc_summary.py +
+    tools/refresh_profiles.sh): this round's if present, else the previous round's."""
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(base, name)) as f:
+                return json.load(f)["kernels"], name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def _pmc_traffic(kernel, table=None):
+    """HBM bytes per launch of `kernel` from the PMC table; None when the profile has no such kernel.
+    Several instantiations matching the label are launch-weighted."""
+    if table is None:
+        table, _ = _pmc_table()
+    if table is None:
         return None
-    frag = _mangled_fragment(kernel)
+    frag = _mangled_fragment(kernel.split(" +")[0])
     tot = n = 0.0
     for name, row in table.items():
         if frag in name or kernel in name:
@@ -180,85 +239,66 @@ def _pmc_traffic(kernel):
     return tot / n if n else None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50, help="timed denoising steps (default: one 50-step DDIM sample)")
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
-    ap.add_argument("--hoist-invariant", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--serial-branches", action="store_true",
-                    help="run ControlNet branches and the UNet encoder on one stream (default: 3 streams)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--parallelism", default="scenes", choices=["scenes", "cfg-split"],
-                    help="scenes: every rank denoises its own scene(s), no data-path collective (default, weak "
-                         "scaling); cfg-split: rank pairs share a scene, one CFG half each, and all-gather the "
-                         "noise prediction every step (single-scene latency mode, needs an even --gpus)")
-    ap.add_argument("--tune-cache", default=os.environ.get("DD_TUNE_CACHE"),
-                    help="load the tile/split-K table from this file if present, write it after warm-up "
-                         "(default: the tracked dualdiff_amd/tuned/gfx950.json is loaded, nothing is written)")
-    ap.add_argument("--retune", action="store_true",
-                    help="ignore the tracked table, time every shape again and write the result to --tune-cache "
-                         "(default target: dualdiff_amd/tuned/gfx950.json, merged with its other entries)")
-    args = ap.parse_args()
+def _roofline_row(name, d, table):
+    """One kernel class: launches, average duration, algorithmic work per launch, the roof its ALGORITHMIC
+    intensity puts it under (ridge = MFMA peak / HBM peak), achieved rate and fraction, PMC traffic."""
+    avg_s = d["ms"] / d["count"] * 1e-3
+    tflops = d["flops"] / d["count"] / avg_s / 1e12
+    gbps = d["bytes"] / d["count"] / avg_s / 1e9
+    ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
+    hbm = d["flops"] / max(d["bytes"], 1.0) < ridge
+    return {"kernel": name, "launches_per_step": d["count"], "avg_us": round(avg_s * 1e6, 2),
+            "ms_per_step": round(d["ms"], 4), "bound": "hbm" if hbm else "mfma",
+            "achieved": round(gbps if hbm else tflops, 1), "unit": "GB/s" if hbm else "TFLOP/s",
+            "frac": round(gbps / PEAK_HBM_GBPS if hbm else tflops / PEAK_MFMA_TFLOPS, 4),
+            "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
+            "algorithmic_flops_per_launch": d["flops"] / d["count"],
+            "traffic": _pmc_traffic(name, table)}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
-                         "there is no CPU fallback for the measured path")
-    # DD_BENCH_SHARE_GPU=1 + DD_BENCH_BACKEND=gloo: plumbing test of the N > 1 path on a 1-GPU box
-    # (all ranks on cuda:0, bookkeeping collectives over gloo) — never a measurement.
-    share = os.environ.get("DD_BENCH_SHARE_GPU") == "1"
-    backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
-    dev_index = 0 if share else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
 
+def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline):
+    """Builds the models in `dtype_name`, captures the step, times args.steps steps; returns a dict."""
     from dualdiff_amd import ops as O
     from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
-
-    if args.retune:
-        O.forget_tuned()
-        args.tune_cache = args.tune_cache or O.TUNE_TABLE_PATH
-    elif args.tune_cache and os.path.exists(args.tune_cache):
-        O.load_tuned(args.tune_cache)
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
     unet, cns = build_models(dtype, device)
-    cfg_kw = {}
-    pairs = 1
+    kw, pairs, shard_desc = {}, 1, None
+    graph = not args.no_graph
     if args.parallelism == "cfg-split":
         if dist is None or world % 2:
             raise SystemExit("--parallelism cfg-split needs an even number of ranks (>= 2)")
         from dualdiff_amd.parallel import cfg_all_gather, cfg_pair_groups
         my_group = cfg_pair_groups(world)[rank // 2]
-        cfg_kw = {"cfg_half": rank % 2, "cfg_exchange": lambda e: cfg_all_gather(e, my_group)}
+        kw = {"cfg_half": rank % 2, "cfg_exchange": lambda e: cfg_all_gather(e, my_group)}
         pairs = 2
+    elif args.parallelism == "view-split":
+        # ONE scene over all ranks (single-scene latency): CFG halves x view shards (even world) or view shards
+        # holding both halves (odd world); neighbour K/V by p2p inside the half group, CFG pair all-gather.
+        if dist is None:
+            raise SystemExit("--parallelism view-split needs >= 2 ranks")
+        from dualdiff_amd.parallel import (HaloExchange, ViewShard, ViewSplitPlan, cfg_all_gather, view_split_groups)
+        plan = ViewSplitPlan(world, rank, PAIR)
+        halves, pair_groups = view_split_groups(world, plan.cfg_split)
+        kw = {"view_shard": ViewShard(plan, HaloExchange(plan, halves[plan.half or 0]))}
+        if plan.cfg_split:
+            grp = pair_groups[plan.shard]
+            kw.update({"cfg_half": plan.half, "cfg_exchange": lambda e: cfg_all_gather(e, grp)})
+        pairs = world                                  # the whole job advances ONE scene
+        graph = graph and os.environ.get("DD_VIEW_SPLIT_GRAPH") == "1"     # p2p inside a captured graph: opt-in
+        shard_desc = "views %s of CFG half %s" % (plan.local, "both" if plan.half is None else plan.half)
     den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
-                      hoist_invariant=args.hoist_invariant, use_graph=not args.no_graph,
-                      parallel_branches=not args.serial_branches, **cfg_kw)
-    graph_ok = not args.no_graph
+                      hoist_invariant=args.hoist_invariant, use_graph=graph,
+                      parallel_branches=not args.serial_branches, **kw)
+    seed = 1234 + (rank // pairs if pairs <= 2 else 0)
     with torch.no_grad():
-        den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank // pairs))
-        if graph_ok:
+        den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=seed))
+        if graph:
             try:
                 den.capture()
             except Exception as e:      # keep measuring on the same HIP kernels, eagerly launched
                 print("[bench] HIP-graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
-                den.use_graph = False
-                graph_ok = False
-                den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=1234 + rank // pairs))
+                den.use_graph = graph = False
+                den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=seed))
 
         def barrier():
             torch.cuda.synchronize()
@@ -281,7 +321,7 @@ def main():
         finite = bool(torch.isfinite(den.latents.float()).all().item())
 
         roofline = None
-        if rank == 0 and not args.no_roofline:
+        if rank == 0 and want_roofline:
             timer = O.KernelTimer()
             timer.calibrate()                 # empty-bracket event overhead, subtracted per launch
             O.set_timer(timer)
@@ -291,32 +331,95 @@ def main():
             den.parallel_branches = par
             O.set_timer(None)
             summ = timer.summary()
-            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            avg_s = d["ms"] / d["count"] * 1e-3
-            tflops = d["flops"] / d["count"] / avg_s / 1e12
-            gbps = d["bytes"] / d["count"] / avg_s / 1e9
-            # the bound is the roof the kernel's ALGORITHMIC intensity puts it under
-            ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
-            hbm_bound = d["flops"] / max(d["bytes"], 1.0) < ridge
-            roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
-                        "launches_per_step": d["count"], "avg_us": avg_s * 1e6,
+            table, table_name = _pmc_table()
+            rows = sorted((_roofline_row(k, v, table) for k, v in summ.items()), key=lambda r: -r["ms_per_step"])
+            # the dominant kernel = the MFMA/HBM-classified symbol with the largest total time
+            top = dict(rows[0])
+            total_ms = sum(r["ms_per_step"] for r in rows)
+            top.update({"peak": PEAK_HBM_GBPS if top["bound"] == "hbm" else PEAK_MFMA_TFLOPS,
                         "event_overhead_us_subtracted": timer.overhead_ms * 1e3,
-                        "share_of_timed_kernels": d["ms"] / sum(v["ms"] for v in summ.values()),
-                        "achieved": gbps if hbm_bound else tflops,
-                        "peak": PEAK_HBM_GBPS if hbm_bound else PEAK_MFMA_TFLOPS,
-                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                        "frac": gbps / PEAK_HBM_GBPS if hbm_bound else tflops / PEAK_MFMA_TFLOPS,
-                        "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
-                        "algorithmic_flops_per_launch": d["flops"] / d["count"],
-                        "other_roof_frac": tflops / PEAK_MFMA_TFLOPS if hbm_bound else gbps / PEAK_HBM_GBPS,
-                        "traffic": _pmc_traffic(name)}
+                        "share_of_timed_kernels": top["ms_per_step"] / total_ms,
+                        "timed_kernels_ms_per_step": total_ms, "pmc_table": table_name,
+                        "tuned_table": os.path.relpath(args.tune_cache or O.TUNE_TABLE_PATH, ROOT),
+                        "classes": rows})
+            roofline = top
             if os.environ.get("DD_BENCH_KERNEL_TABLE"):
-                rows = sorted(summ.items(), key=lambda kv: -kv[1]["ms"])
                 with open(os.environ["DD_BENCH_KERNEL_TABLE"], "w") as f:
-                    for k, v in rows:
-                        f.write("%-70s n=%4d total=%9.3f ms avg=%8.1f us  %7.1f TFLOP/s\n" % (
-                            k, v["count"], v["ms"], v["ms"] / v["count"] * 1e3,
-                            v["flops"] / (v["ms"] * 1e-3) / 1e12))
+                    for r in rows:
+                        f.write("%-72s n=%4d total=%8.3f ms avg=%8.1f us  %-4s %8.1f %-8s frac=%.3f\n" % (
+                            r["kernel"], r["launches_per_step"], r["ms_per_step"], r["avg_us"], r["bound"],
+                            r["achieved"], r["unit"], r["frac"]))
+    del den, unet, cns
+    torch.cuda.empty_cache()
+    return {"elapsed": elapsed, "finite": finite, "roofline": roofline, "graph": graph, "pairs": pairs,
+            "shard": shard_desc}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50, help="timed denoising steps (default: one 50-step DDIM sample)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
+                    help="storage / MFMA input type of the headline number (fp32 accumulation either way).  fp16 is "
+                         "the reference's eval dtype and what BASELINE.json's metric string names; the other 16-bit "
+                         "type is measured in the same run and reported under `other_dtype` (--single-dtype skips it)")
+    ap.add_argument("--single-dtype", action="store_true")
+    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
+    ap.add_argument("--hoist-invariant", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="run ControlNet branches and the UNet encoder on one stream (default: 3 streams)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=1, help="full config-2 oracle steps timed for cpu_baseline")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--parallelism", default="scenes", choices=["scenes", "cfg-split", "view-split"],
+                    help="scenes: every rank denoises its own scene(s), no data-path collective (default, weak "
+                         "scaling); cfg-split: rank pairs share a scene, one CFG half each, and all-gather the "
+                         "noise prediction every step; view-split: ALL ranks share one scene — CFG halves x view "
+                         "shards, neighbour-view K/V exchanged point-to-point in every transformer block "
+                         "(single-scene latency modes, strong scaling)")
+    ap.add_argument("--tune-cache", default=os.environ.get("DD_TUNE_CACHE"),
+                    help="load the tile/split-K table from this file if present, write it after warm-up "
+                         "(default: the tracked dualdiff_amd/tuned/gfx950.json is loaded, nothing is written)")
+    ap.add_argument("--retune", action="store_true",
+                    help="ignore the tracked table, time every shape again and write the result to --tune-cache "
+                         "(default target: dualdiff_amd/tuned/gfx950.json, merged with its other entries)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
+                         "there is no CPU fallback for the measured path")
+    # DD_BENCH_SHARE_GPU=1 + DD_BENCH_BACKEND=gloo: plumbing test of the N > 1 path on a 1-GPU box
+    # (all ranks on cuda:0, collectives over gloo with host staging) — never a measurement.
+    share = os.environ.get("DD_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+    from dualdiff_amd import ops as O
+    if args.retune:
+        O.forget_tuned()
+        args.tune_cache = args.tune_cache or O.TUNE_TABLE_PATH
+    elif args.tune_cache and os.path.exists(args.tune_cache):
+        O.load_tuned(args.tune_cache)
+
+    res = measure(args, args.dtype, device, dist, world, rank, backend, not args.no_roofline)
+    other_name = "bf16" if args.dtype == "fp16" else "fp16"
+    other = None
+    if not args.single_dtype and args.parallelism == "scenes":
+        other = measure(args, other_name, device, dist, world, rank, backend, False)
 
     if rank != 0:
         if dist is not None:
@@ -324,28 +427,38 @@ def main():
         return
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-    scenes_total = args.scenes * world // pairs
-    steps_total = args.steps * scenes_total
-    value = steps_total / elapsed
+        cpu = cpu_baseline(args.cpu_steps)
+    pairs = res["pairs"]
+    scenes_total = max(1, args.scenes * world // pairs)
+    value = args.steps * scenes_total / res["elapsed"]
     step_tflop = (12 * GF_UNET + 24 * GF_CNET) / 1e3
+    par = {"scenes": "scene-sharded x%d (no data-path collective)" % world,
+           "cfg-split": "CFG halves split over rank pairs x%d (all-gather of the noise prediction per step)" % (world // 2),
+           "view-split": "one scene over %d ranks: CFG halves x view shards, p2p neighbour-view K/V exchange per "
+                         "transformer block + CFG pair all-gather per step" % world}[args.parallelism]
     out = {
         "metric": _metric_name(),
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3 / args.scenes, "higher_is_better": True, "scaling": "weak" if pairs == 1 else "strong",
+        "ms_per_step": res["elapsed"] / args.steps * 1e3 / args.scenes, "higher_is_better": True,
+        "scaling": "weak" if pairs == 1 else "strong",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 6-view 224x400 (28x50 latents) multiview UNet + 2 ControlNet "
                                "branches (ORS panorama + ORS-3D, SFA on), CFG 2.0 -> 12 view-instances/scene, "
                                "DDIM-50 schedule, random-init weights",
-                   "scenes_per_gpu": args.scenes, "parallelism": ("scene-sharded x%d (no data-path collective)" % world) if pairs == 1 else
-                                  ("CFG halves split over rank pairs x%d (all-gather of the noise prediction per step)" % (world // 2)),
-                   "hip_graph": graph_ok, "streams": 1 if args.serial_branches else 3, "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
+                   "scenes_per_gpu": args.scenes, "parallelism": par,
+                   "hip_graph": res["graph"], "streams": 1 if args.serial_branches else 3,
+                   "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
                    "algorithmic_tflop_per_step": step_tflop},
         "model_tflops": value * step_tflop,
-        "outputs_finite": finite,
-        "roofline": roofline,
+        "outputs_finite": res["finite"],
+        "roofline": res["roofline"],
         "cpu_baseline": cpu,
     }
+    if other is not None:
+        ov = args.steps * scenes_total / other["elapsed"]
+        out["other_dtype"] = {"dtype": other_name, "value": ov, "unit": "steps/s",
+                              "ms_per_step": other["elapsed"] / args.steps * 1e3 / args.scenes,
+                              "outputs_finite": other["finite"]}
     if cpu:
         out["speedup_vs_cpu"] = value / cpu["value"]
     print(json.dumps(out))

@@ -44,6 +44,7 @@ struct GemmParams {
   float* stat_out;                       // [rows][n/32][2] row sum / sum of squares of the stored values, or NULL
   const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
   int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
+  const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
 };
 
 template <typename T>
@@ -1095,6 +1096,297 @@ void dd_conv3s_kernel(const GemmParams p) {
                                nullptr, nullptr, tile);
 }
 
+// =============================================================================================
+// Kernel family 4: ROW-PANEL GEMM for the transformer projections (dense, K = C in {320, 640, 1280}).
+//
+// The C x C / C x 3C projections of a transformer block (to_q / QKV, to_out, proj_in; 16800 .. 336 rows)
+// are far too small for the tiled families: a 64x64 tile re-reads both operands through L2 once per tile
+// and a 10-20 step K loop with a barrier per step leaves the kernel latency-bound (~11 us where the bytes
+// take 3-6).  Here ONE workgroup per CU owns a column slice of BN = 4 waves x TN x 16 outputs for a whole
+// group of rows:
+//   * its weight slice lives in REGISTERS for the kernel's lifetime — every wave keeps the MFMA fragments
+//     of its TN x 16 weight rows over the full K (TN * K/32 x 4 VGPRs: 200-320 of the 512 a one-wave-per-
+//     SIMD kernel has), loaded once by buffer loads straight from global memory;
+//   * the rows stream through LDS as PANELS of BM = TM x 16 rows x full K (LDS-DMA ring, the next panel
+//     lands while the current one is multiplied); a panel needs no K loop synchronisation at all: one
+//     counted vmcnt wait + one barrier, then K/32 MFMA steps whose only LDS traffic is the A fragments;
+//   * optional LayerNorm PROLOGUE (`ln_gamma`): the panel holds the un-normalised rows and is normalised in
+//     place (two-pass fp32 statistics, result rounded to T — the arithmetic of dd_layernorm_sub_kernel)
+//     before the MFMAs, which removes the LayerNorm launch and its HBM round trip in front of every
+//     Q / QKV projection (norm1 / norm2 / norm4 of blocks.py:150-222);
+//   * 2-D decomposition p row groups x q column slices with p * q <= 256 workgroups: per-CU bytes are
+//     |W| / q + |A| / p instead of (rows / 64) x (N / 64) tile pairs.
+// Epilogue: bias, alpha, residual, accumulate, head-major planes (+ scale) like the other families.
+// Requirements (host-checked): no a2 / conv / GEGLU / split-K / rowvec, N % BN == 0.
+// =============================================================================================
+template <typename T, int VW>
+__device__ __forceinline__ void rp_store_vec(const GemmParams& p, int64_t row, int col, float (&v)[VW]) {
+  using VT = typename std::conditional<VW == 8, u32x4, u32x2>::type;
+  T* dst;
+  if (p.hm_d) {
+    const int plane = col / p.hm_d;
+    if (plane < p.hm_planes) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] *= p.hm_scale;
+    }
+    dst = reinterpret_cast<T*>(p.out) + ((int64_t)plane * p.rows + row) * p.hm_d + (col - plane * p.hm_d);
+  } else {
+    dst = reinterpret_cast<T*>(p.out) + row * p.ldc + col;
+  }
+  T tmp[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) tmp[e] = (T)v[e];
+  VT pk;
+  __builtin_memcpy(&pk, tmp, sizeof(VT));
+  *reinterpret_cast<VT*>(dst) = pk;
+}
+
+template <typename T, int VW>
+__device__ __forceinline__ void rp_load_vec(const T* src, float (&f)[VW]) {
+  using VT = typename std::conditional<VW == 8, u32x4, u32x2>::type;
+  const VT raw = *reinterpret_cast<const VT*>(src);
+  T tmp[VW];
+  __builtin_memcpy(tmp, &raw, sizeof(VT));
+#pragma unroll
+  for (int e = 0; e < VW; ++e) f[e] = (float)tmp[e];
+}
+
+template <typename T, int KS, int TN, int TM, int NBUF, bool LN>
+__global__ __launch_bounds__(256)
+void dd_gemm_rp_kernel(const GemmParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  constexpr int K = KS * 32;
+  constexpr int NSUB = K / 64;                     // 64-column sub-tiles of a panel
+  constexpr int BM = TM * 16;
+  constexpr int BNW = TN * 16;                     // output columns per wave
+  constexpr int BN = 4 * BNW;
+  constexpr int PANEL = BM * K;                    // elements per panel buffer
+  constexpr int PIECES = (BM / 8) * NSUB;          // 1-KB DMA pieces (8 rows x 128 B) per panel
+  constexpr int PPW = (PIECES + 3) / 4;            // per wave; surplus pieces land in a dump slot
+  constexpr int VW = (TN % 2 == 0) ? 8 : 4;        // channels per epilogue vector (16 B needs an even TN)
+  constexpr int NG = 4 * TN / VW;                  // epilogue vectors per lane and row
+  constexpr int NSTORE = TM * NG;                  // store instructions per wave and (full) panel
+  static_assert(KS % 2 == 0 && NBUF >= 2, "K must be a multiple of 64");
+  static_assert(NSTORE <= 63 && (NBUF - 1) * PPW + NSTORE <= 63, "vmcnt is a 6-bit counter");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* ring = reinterpret_cast<T*>(smem);                         // [NBUF][NSUB][BM][64], chunk-swizzled
+  T* dump = ring + NBUF * PANEL;                                // [4 waves][512]: landing zone of surplus pieces
+  T* lnv = dump + 4 * 512;                                      // [2][K]: gamma | beta
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- work decomposition: (row group, column slice); slices of one row group sit on one XCD ----
+  const int nwg = gridDim.x;
+  const int unit = xcd_remap(blockIdx.x, nwg);
+  const int qn = p.tiles_n;                                     // column slices
+  const int pi = unit / qn, qi = unit - pi * qn;
+  const int panels_total = (p.rows + BM - 1) / BM;
+  const int ppg = p.k_per_split;                                // panels per row group (host: ceil)
+  const int panel0 = pi * ppg;
+  const int npan = min(ppg, panels_total - panel0);             // >= 1 by construction
+  const int col0 = qi * BN + wave * BNW;
+
+  // ---- weight fragments -> registers (issued first: the longest fetch of the kernel) ------------
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+  const int fr = lane & 15, fq = lane >> 4;
+  V8 wreg[TN][KS];
+  {
+    // weight row permutation of the other families: lane group q ends up with 4*TN CONSECUTIVE channels
+    const int loc0 = (fr >> 2) * (4 * TN) + (fr & 3);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = col0 + loc0 + tn * 4;
+      const uint32_t vo = n < p.n ? (uint32_t)n * (uint32_t)(K * 2) + (uint32_t)fq * 16u : DD_OOB;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        wreg[tn][ks] = dd_as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(rs_w, vo + ks * 64, 0, 0));
+    }
+  }
+
+  // ---- panel DMA tables (constant per lane; a panel moves only the scalar row offset) -----------
+  const int lrow8 = lane >> 3;
+  uint32_t ptab[PPW];                               // byte offset inside a panel's source rows
+  int prow[PPW];                                    // panel row this lane fetches (-1: surplus piece)
+  int pdst[PPW];                                    // LDS element offset of the piece inside a buffer
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int pc = j * 4 + wave;
+    if (pc < PIECES) {
+      const int sub = pc / (BM / 8), rb = pc - sub * (BM / 8);
+      const int row = rb * 8 + lrow8;
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      prow[j] = row;
+      ptab[j] = (uint32_t)row * (uint32_t)p.lda * 2u + (uint32_t)sub * 128u + (uint32_t)lc * 16u;
+      pdst[j] = (sub * BM + rb * 8) * 64;
+    } else {
+      prow[j] = -1; ptab[j] = DD_OOB; pdst[j] = -1;
+    }
+  }
+  auto issue_panel = [&](int pl, int buf) __attribute__((always_inline)) {
+    const int r0 = (panel0 + pl) * BM;
+    const uint32_t so = (uint32_t)r0 * (uint32_t)p.lda * 2u;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const bool ok = prow[j] >= 0 && r0 + prow[j] < p.rows;
+      T* dst = pdst[j] >= 0 ? ring + buf * PANEL + pdst[j] : dump + wave * 512;
+      bdma16(rs_a, ok ? ptab[j] : DD_OOB, so, dst);
+    }
+  };
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b)
+    if (b < npan) issue_panel(b, b);
+
+  if (LN) {                                         // gamma | beta -> LDS (read per chunk in the prologue)
+    for (int i = tid; i < 2 * K / 8; i += 256) {
+      const T* src = i < K / 8 ? reinterpret_cast<const T*>(p.ln_gamma) + i * 8
+                               : reinterpret_cast<const T*>(p.ln_beta) + (i - K / 8) * 8;
+      dd_st16(lnv + i * 8, dd_ld16(src));
+    }
+  }
+  // epilogue constants
+  const int ecol0 = col0 + fq * (4 * TN);
+  float ebias[NG][VW];
+  if (p.bias) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.bias) + ecol0 + g * VW, ebias[g]);
+  }
+  const int fswz = (lane >> 1) & 7;
+
+  for (int pl = 0; pl < npan; ++pl) {
+    const int buf = pl % NBUF;
+    // panel pl must have landed.  Younger operations of this wave: the DMA pieces of up to NBUF-2 later
+    // panels and the NSTORE stores of the previous panel's epilogue (full panels only: a partial panel is
+    // the last one of the whole problem) — counted, so nothing drains.
+    if (pl == 0) {
+      wait_vmcnt<0>();                              // first panel + the weight fragments
+    } else {
+      const int ahead = min(npan - 1 - pl, NBUF - 2);
+      if (ahead <= 0) wait_vmcnt<NSTORE>();
+      else if (ahead == 1 || NBUF <= 3) wait_vmcnt<NSTORE + (NBUF > 2 ? 1 : 0) * PPW>();
+      else wait_vmcnt<NSTORE + (NBUF > 3 ? 2 : 0) * PPW>();
+    }
+    __builtin_amdgcn_s_barrier();                   // everyone's pieces landed; slot (pl-1) % NBUF is free
+    if (pl + NBUF - 1 < npan) issue_panel(pl + NBUF - 1, (pl + NBUF - 1) % NBUF);
+    T* ab = ring + buf * PANEL;
+
+    if (LN) {
+      // LayerNorm in place: BM/4 rows per wave, LPR lanes per row, 16-B chunks round-robin over the lanes
+      constexpr int RPW = BM / 4, LPR = 64 / RPW, NCH = K / 8;
+      const int row = wave * RPW + lane / LPR;
+      const int sub = lane % LPR;
+      const int rsw = (row >> 1) & 7;
+      auto chunk_ptr = [&](int ci) __attribute__((always_inline)) {
+        return ab + ((ci >> 3) * BM + row) * 64 + (((ci & 7) ^ rsw) << 3);
+      };
+      float s = 0.f;
+      for (int ci = sub; ci < NCH; ci += LPR) {
+        float f[8];
+        dd_unpack8<T>(dd_ld16(chunk_ptr(ci)), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * (1.0f / (float)K);
+      float ss = 0.f;
+      for (int ci = sub; ci < NCH; ci += LPR) {
+        float f[8];
+        dd_unpack8<T>(dd_ld16(chunk_ptr(ci)), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; ss += d * d; }
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float rstd = rsqrtf(ss * (1.0f / (float)K) + p.ln_eps);
+      for (int ci = sub; ci < NCH; ci += LPR) {
+        float f[8], ga[8], be[8];
+        dd_unpack8<T>(dd_ld16(chunk_ptr(ci)), f);
+        dd_unpack8<T>(dd_ld16(lnv + ci * 8), ga);
+        dd_unpack8<T>(dd_ld16(lnv + K + ci * 8), be);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * ga[e] + be[e];
+        dd_st16(chunk_ptr(ci), dd_pack8<T>(f));
+      }
+      __syncthreads();
+    }
+
+    // ---- MFMAs over the whole K: A fragments from LDS, weight fragments from registers ----------
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* xs = ab + fr * 64;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cofs = ((fq + 4 * (ks & 1)) ^ fswz) << 3;
+      V8 xf[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = dd_as_v8<T>(dd_ld16(xs + ((ks >> 1) * BM + j * 16) * 64 + cofs));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wreg[i][ks], xf[j], acc[i][j]);
+    }
+
+    // ---- epilogue: every global read before the first store (out may alias res) ------------------
+    const int r0 = (panel0 + pl) * BM;
+    float eres[TM][NG][VW], eacc[TM][NG][VW];
+    if (p.res) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int64_t rowc = min(r0 + j * 16 + fr, p.rows - 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.res) + rowc * p.ldres + ecol0 + g * VW, eres[j][g]);
+      }
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int64_t rowc = min(r0 + j * 16 + fr, p.rows - 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.out) + rowc * p.ldc + ecol0 + g * VW, eacc[j][g]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int row = r0 + j * 16 + fr;
+      if (row < p.rows) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          float v[VW];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) {
+            const int c = g * VW + e;                    // channel inside the lane's 4*TN run
+            v[e] = acc[c >> 2][j][c & 3];
+          }
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] += ebias[g][e];
+          }
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[e] *= p.alpha;
+          if (p.res) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] += eres[j][g][e];
+          }
+          if (p.accumulate) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] += eacc[j][g][e];
+          }
+          rp_store_vec<T, VW>(p, row, ecol0 + g * VW, v);
+        }
+      }
+    }
+  }
+}
+
 // split-K: sum the fp32 partial slabs and run the fused epilogue.
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -1154,6 +1446,10 @@ constexpr TileCfg kTiles[] = {
     {36, 2, 2, 4, 4, -1, "conv3s 128x128/w3"},
     {37, 2, 2, 6, 2, -1, "conv3s 192x64/g3"},     // taps in groups of three: one barrier per 72 MFMAs
     {38, 2, 2, 4, 2, -1, "conv3s 128x64/g3"},
+    // stages == -2: row-panel family (dd_gemm_rp_kernel; dense, K in {320, 640, 1280}): tm = 16-row MFMA blocks
+    // per panel; wn / tn follow from K (5 x 16 columns per wave at K = 320, 2 x 16 otherwise)
+    {41, 1, 4, 1, 0, -2, "rowpanel 16"},
+    {42, 1, 4, 2, 0, -2, "rowpanel 32"},
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1180,6 +1476,9 @@ bool dma_ok(const dd_gemm_desc* d) {
   }
   return ok;
 }
+
+// row-panel family: 16-column MFMA blocks per wave for a given K (0 = K not covered)
+inline int rp_tn(int k) { return k == 320 ? 5 : (k == 640 || k == 1280) ? 2 : 0; }
 
 Plan make_plan(const dd_gemm_desc* d) {
   const bool geglu = d->epilogue == DD_EPI_GEGLU;
@@ -1208,6 +1507,32 @@ Plan make_plan(const dd_gemm_desc* d) {
       for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == twin[ti < 4 ? ti : 3]) { ti = i; break; }
     }
     if (kTiles[ti].stages <= 0 || !dma_ok(d)) { pl.unsupported = true; return pl; }
+  }
+  if (d->ln_gamma && (ti < 0 || kTiles[ti].stages != -2)) {   // the LayerNorm prologue lives in the row-panel family
+    if (d->tile > 0) { pl.unsupported = true; return pl; }
+    for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 41) ti = i;
+  }
+  if (kTiles[ti].stages == -2) {                     // row-panel GEMM
+    const TileCfg& t = kTiles[ti];
+    const int tn = rp_tn(d->k);
+    const int bn = 4 * tn * 16, bm = t.tm * 16;
+    const bool ok = tn > 0 && !d->conv && !d->a2 && !geglu && d->epilogue == DD_EPI_NONE && !d->rowvec &&
+                    !d->ln_colsum && !d->ln_stats_out && !d->out_f32 && d->split_k <= 1 && (d->n % bn) == 0 &&
+                    (t.tm == 1 || d->k <= 640) && (!d->ln_gamma || d->ln_beta) &&
+                    (int64_t)d->rows * d->lda < ((int64_t)1 << 30) && (int64_t)d->n * d->k < ((int64_t)1 << 30);
+    if (!ok) { pl.unsupported = true; return pl; }
+    const int panels = ceil_div(d->rows, bm);
+    const int q = d->n / bn;
+    int pg = kNumCU / q;
+    if (pg < 1) pg = 1;
+    if (pg > panels) pg = panels;
+    const int ppg = ceil_div(panels, pg);
+    pl.tile_idx = ti;
+    pl.tiles_m = ceil_div(panels, ppg);
+    pl.tiles_n = q;
+    pl.split = 1;
+    pl.k_per_split = ppg;                            // panels per row group
+    return pl;
   }
   if (kTiles[ti].stages < 0) {                       // direct small-image conv
     const TileCfg& t = kTiles[ti];
@@ -1302,8 +1627,42 @@ int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
+template <typename T, int KS, int TN, int TM, int NBUF>
+int launch_rp(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  constexpr size_t smem = ((size_t)NBUF * TM * 16 * KS * 32 + 4 * 512 + 2 * KS * 32) * sizeof(T);
+  static_assert(smem <= 160 * 1024, "LDS");
+  dim3 grid(pl.tiles_m * pl.tiles_n);
+  if (p.ln_gamma) {
+    auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, true>;
+    static std::atomic<uint64_t> attr_done{0};
+    dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  } else {
+    auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, false>;
+    static std::atomic<uint64_t> attr_done{0};
+    dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  }
+  return dd_check_launch();
+}
+
+template <typename T>
+int launch_rp_k(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  const int tm = kTiles[pl.tile_idx].tm;
+  switch (p.k) {
+    case 320: return tm == 1 ? launch_rp<T, 10, 5, 1, 3>(p, pl, s) : launch_rp<T, 10, 5, 2, 3>(p, pl, s);
+    case 640: return tm == 1 ? launch_rp<T, 20, 2, 1, 3>(p, pl, s) : launch_rp<T, 20, 2, 2, 3>(p, pl, s);
+    case 1280: if (tm == 1) return launch_rp<T, 40, 2, 1, 3>(p, pl, s); break;
+  }
+  return DD_ERR_UNSUPPORTED;
+}
+
 template <typename T, bool CONV, bool GEGLU>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  if (kTiles[pl.tile_idx].stages == -2) {
+    if constexpr (!CONV && !GEGLU) return launch_rp_k<T>(p, pl, s);
+    return DD_ERR_UNSUPPORTED;
+  }
   switch (kTiles[pl.tile_idx].id) {
     case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
     case 33: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 8>(p, pl, s); break;
@@ -1366,6 +1725,11 @@ int validate(const dd_gemm_desc* d) {
     if (!d->ln_bias || d->conv || d->a2 || d->bias) return DD_ERR_BAD_ARG;
     if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
     if (!dd_aligned16(d->ln_colsum) || !dd_aligned16(d->ln_bias) || (d->lda & 7)) return DD_ERR_BAD_ARG;
+  }
+  if (d->ln_gamma) {                                   // direct LayerNorm prologue (row-panel family)
+    if (!d->ln_beta || d->conv || d->a2 || d->ln_colsum) return DD_ERR_BAD_ARG;
+    if (!dd_aligned16(d->ln_gamma) || !dd_aligned16(d->ln_beta) || (d->lda & 7)) return DD_ERR_BAD_ARG;
+    if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
   }
   if (d->rows <= 0 || d->n <= 0 || d->k <= 0) return DD_ERR_BAD_ARG;
   if ((d->k & 7) || (d->n & 7) || (d->ldc & 7)) return DD_ERR_BAD_ARG;
@@ -1431,6 +1795,12 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   const Plan pl = make_plan(d);
   if (pl.unsupported) return "unsupported";
   const TileCfg& t = kTiles[pl.tile_idx];
+  if (t.stages == -2) {
+    snprintf(g_kname, sizeof(g_kname), "dd_gemm_rp_kernel<%s, %d, %d, %d, 3, %s> split=1 grid=%dx%d tile=%s",
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", d->k / 32, rp_tn(d->k), t.tm, d->ln_gamma ? "true" : "false",
+             pl.tiles_m, pl.tiles_n, t.name);
+    return g_kname;
+  }
   if (t.stages < 0) {
     snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
              d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4))), pl.split, pl.tiles_m, pl.tiles_n, t.name);
@@ -1456,6 +1826,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.ln_colsum = reinterpret_cast<const float*>(d->ln_colsum);
   p.ln_bias = reinterpret_cast<const float*>(d->ln_bias);
   p.ln_eps = d->ln_eps;
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta;
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;

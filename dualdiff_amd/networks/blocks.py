@@ -38,6 +38,9 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         self.attn4 = Attention(dim, dim, num_attention_heads, attention_head_dim)
         self.connector = Linear(dim, dim)
         self._maps = {}
+        # dualdiff_amd.parallel.ViewShard when the views of a scene are spread over several GPUs
+        # (UNet2DConditionModelMultiview.set_view_shard); None = all n_cam views are local
+        self.view_shard = None
 
     # `connector(to_out(o))` is two Linear layers with nothing in between (blocks.py:203-222): they
     # run as ONE GEMM with W = Wc Wo and b = Wc (nb b_o) + b_c, folded in fp32 when the weights change.
@@ -76,22 +79,53 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             self._maps[key] = maps
         return self._maps[key]
 
+    def _attn4_sharded(self, h, batch, l):
+        """attn4 when this rank holds only `n_local` of the n_cam views (SURVEY §8e view split): Q/K/V of
+        the local views are projected as usual; their K/V go into the first slots of a slot-major buffer
+        (slot, half/scene, [K heads | V heads], l, d) whose remaining slots the exchange fills with the
+        neighbours' K/V from other ranks — a view's K/V of one level is one contiguous message — and the
+        two neighbour attentions read the buffer through kv_batch_map exactly as in the unsharded case
+        (same kernel, same per-(instance, head) K/V values -> the same bits)."""
+        a, sh = self.attn4, self.view_shard
+        hd, d = a.heads, a.dim_head
+        if not (layers.HEAD_MAJOR and a.to_q.bias is None):
+            raise NotImplementedError("view split needs the head-major bias-free attn4 projection")
+        nloc = sh.n_local
+        if batch % nloc:
+            raise ValueError("%d instances are not a multiple of the %d local views" % (batch, nloc))
+        nbat = batch // nloc
+        qkv = a.project_qkv(h, self.norm4, head_major=True)                       # (3 * hd, batch * l, d)
+        kv = torch.empty((sh.plan.n_slots, nbat, 2 * hd, l, d), dtype=h.dtype, device=h.device)
+        kv[:nloc].copy_(qkv[hd:].reshape(2 * hd, nbat, nloc, l, d).permute(2, 1, 0, 3, 4))
+        sh.exchange(kv)
+        flat = kv.reshape(sh.plan.n_slots * nbat, 2 * hd, l, d)
+        k4, v4 = flat[:, :hd], flat[:, hd:]
+        maps = sh.maps(nbat, h.device)
+        o = None
+        for j, mp in enumerate(maps):
+            o = O.attention(qkv[:hd], k4, v4, batch, l, l, hd, d, a.scale, kv_batch_map=mp, out=o,
+                            accumulate=j > 0, q_prescaled=True)
+        return o, len(maps)
+
     def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
         h = self._attn(self.attn1, self.norm1, h, batch, l)
         h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
         # ---- neighbour-view attention ------------------------------------------------------
         a = self.attn4
         c = a.inner_dim
-        hm = layers.HEAD_MAJOR and a.to_q.bias is None
-        qkv = a.project_qkv(h, self.norm4, head_major=hm)
-        q, k, v = ((qkv[:a.heads], qkv[a.heads:2 * a.heads], qkv[2 * a.heads:]) if hm
-                   else (qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]))
-        maps = self.neighbour_maps(batch, h.device)
-        o = None
-        for j, mp in enumerate(maps):
-            o = O.attention(q, k, v, batch, l, l, a.heads, a.dim_head, a.scale, kv_batch_map=mp, out=o,
-                            accumulate=j > 0, q_prescaled=hm)
-        nb = len(maps)
+        if self.view_shard is not None:
+            o, nb = self._attn4_sharded(h, batch, l)
+        else:
+            hm = layers.HEAD_MAJOR and a.to_q.bias is None
+            qkv = a.project_qkv(h, self.norm4, head_major=hm)
+            q, k, v = ((qkv[:a.heads], qkv[a.heads:2 * a.heads], qkv[2 * a.heads:]) if hm
+                       else (qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]))
+            maps = self.neighbour_maps(batch, h.device)
+            o = None
+            for j, mp in enumerate(maps):
+                o = O.attention(q, k, v, batch, l, l, a.heads, a.dim_head, a.scale, kv_batch_map=mp, out=o,
+                                accumulate=j > 0, q_prescaled=hm)
+            nb = len(maps)
         if self.fold_connector:
             w, b = self._folded_out(nb)
             h = O.gemm(o, w, b, res=h, ln_stats=want_ln_stats())        # feeds norm3

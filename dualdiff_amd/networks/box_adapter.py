@@ -20,6 +20,12 @@ class XFormersAttnProcessor(HIPAttnProcessor):
     def __init__(self, attention_op=None):
         self.attention_op = attention_op
 
+    @property
+    def chunked(self):
+        """True when SPLIT_SIZE asks for batch chunking: the transformer blocks then call the processor
+        through the diffusers protocol (so that __call__ can chunk) instead of their fused fast path."""
+        return SPLIT_SIZE != -1
+
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, **kw):
         n = hidden_states.shape[0]
         if SPLIT_SIZE != -1 and n > SPLIT_SIZE:

@@ -86,7 +86,10 @@ class Linear(_Cached):
         return O.gemm(x2d, w, self.bias, **kw)
 
     def run_ln(self, x2d, norm, **kw):
-        """LayerNorm(norm) + this Linear as one GEMM on the UN-normalised x2d (fold_layernorm)."""
+        """LayerNorm(norm) + this Linear.  Row-panel GEMM with the LayerNorm as its prologue where the family
+        covers the shape (ln_direct_ok), else the algebraic fold when enabled, else two launches."""
+        if ln_direct_ok(norm, self.in_features, self.out_features, kw):
+            return O.gemm(x2d, self.w2d, self.bias, ln_direct=(norm.weight, norm.bias, norm.eps), **kw)
         if not ln_fold_ok(norm, self.in_features, self.out_features, x2d):
             return self.run(norm.run(x2d), **kw)
         w, ln = fold_layernorm(self.__dict__, "_pk_ln", norm, [self.weight], [self.bias])
@@ -195,6 +198,20 @@ def ln_fold_ok(norm, k, n=None, x=None):
 
 def want_ln_stats():
     return LN_FOLD == "stats"
+
+
+# LayerNorm as the PROLOGUE of the row-panel projection GEMM (dd_gemm_desc.ln_gamma): the panel of un-normalised
+# rows is normalised in LDS before the MFMAs, so norm1 / norm2 / norm4 need no launch of their own and their
+# output never visits HBM.  DD_LN_DIRECT=0 restores LayerNorm kernel + GEMM.
+LN_DIRECT = __import__("os").environ.get("DD_LN_DIRECT", "1") != "0"
+
+
+def ln_direct_ok(norm, k, n, kw=None):
+    if not LN_DIRECT or LN_FOLD != "0" or not isinstance(norm, LayerNorm):
+        return False
+    if kw and (kw.get("epilogue", O.DD_EPI_NONE) != O.DD_EPI_NONE or kw.get("ln_stats") or kw.get("a2") is not None):
+        return False
+    return O.rowpanel_ok(k, n)
 
 
 # Head-major Q / K / V planes + softmax scale folded into Q by the projection epilogue (dd_gemm_desc.
@@ -355,6 +372,17 @@ class Attention(_Cached):
         bh, l, d = t.shape
         return t.reshape(bh // self.heads, self.heads, l, d).permute(0, 2, 1, 3).reshape(bh // self.heads, l, -1)
 
+    def get_attention_scores(self, query, key, attention_mask=None):
+        """diffusers `Attention.get_attention_scores`: softmax(scale * q k^T) on (batch*heads, L, d) tensors,
+        fp32 softmax, probabilities back in the input dtype.  Part of the surface FOREIGN processors call
+        (reference tools/unet_modify.py:30 keeps the probabilities for visualisation); plain torch on the
+        caller's tensors — the built-in processors never come here, they run the flash kernel."""
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is None on the denoising path")
+        scores = torch.baddbmm(torch.empty((), dtype=query.dtype, device=query.device).expand(
+            query.shape[0], query.shape[1], key.shape[1]), query, key.transpose(-1, -2), beta=0, alpha=self.scale)
+        return scores.float().softmax(dim=-1).to(query.dtype)
+
     # fused weights ------------------------------------------------------------------------
     def _fused(self, names):
         key = "_pk_" + "".join(names)
@@ -384,6 +412,9 @@ class Attention(_Cached):
         folded into the GEMM."""
         hm = self._hm(self.heads) if head_major else None
         if norm is not None:
+            if ln_direct_ok(norm, x2d.shape[1], 3 * self.inner_dim):
+                return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")), self._fused_bias(("to_q", "to_k", "to_v")),
+                              ln_direct=(norm.weight, norm.bias, norm.eps), head_major=hm)
             if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim, x2d):
                 return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")),
                               self._fused_bias(("to_q", "to_k", "to_v")), head_major=hm)
@@ -499,7 +530,7 @@ class BasicTransformerBlock(nn.Module):
         """LayerNorm `norm` + `attn` (+ residual h).  The built-in processor folds the LayerNorm
         into the Q(KV) projection and the residual into the out-projection; foreign processors get
         the normalised (B, L, C) tensor through the diffusers protocol."""
-        if isinstance(attn.processor, HIPAttnProcessor):
+        if isinstance(attn.processor, HIPAttnProcessor) and not getattr(attn.processor, "chunked", False):
             st = ln_next and want_ln_stats()          # the output feeds the block's next LayerNorm
             if ctx is None:
                 return attn.run_self(h, batch, l, res=h, norm=norm, ln_stats=st)

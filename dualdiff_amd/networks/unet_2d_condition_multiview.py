@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import ops as O
 from .blocks import BasicMultiviewTransformerBlock
-from .layers import (prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
+from .layers import (BasicTransformerBlock, prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
                      TimestepEmbedding, Timesteps, UNetMidBlock2DCrossAttn, UpBlock2D, as_nchw_view,
                      run_down_block, run_up_block, to_nhwc)
 from .model_base import ModelBase
@@ -33,6 +33,9 @@ _DEFAULT_PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0
 
 
 class UNet2DConditionModelMultiview(ModelBase):
+    # True: `BasicMultiviewTransformerBlock` (attn4 + connector) in every transformer; the plain SD-v1.5
+    # subclass below turns it off
+    multiview = True
     # Side-stream projection of the cross-attention K/V (layers.prefetch_cross_kv).  Measured on MI355X
     # (config 2, graph replay): 66.0 steps/s off vs 62.4 on — the extra stream's small GEMMs delay the
     # main chain more than they shorten it — so it is off; DD_PREFETCH_KV=1 turns it on.
@@ -103,10 +106,13 @@ class UNet2DConditionModelMultiview(ModelBase):
         self.img_size = [int(s) for s in img_size] if img_size is not None else None
         self.trainable_state = trainable_state
         self._new_module = {}
-        pair = neighboring_view_pair if neighboring_view_pair is not None else _DEFAULT_PAIR
-        blk_kw = dict(neighboring_view_pair=pair, neighboring_attn_type=neighboring_attn_type,
-                      zero_module_type=zero_module_type)
-        bcls = BasicMultiviewTransformerBlock
+        if self.multiview:
+            pair = neighboring_view_pair if neighboring_view_pair is not None else _DEFAULT_PAIR
+            blk_kw = dict(neighboring_view_pair=pair, neighboring_attn_type=neighboring_attn_type,
+                          zero_module_type=zero_module_type)
+            bcls = BasicMultiviewTransformerBlock
+        else:
+            blk_kw, bcls = {}, BasicTransformerBlock
 
         c0 = block_out_channels[0]
         ted = c0 * 4
@@ -170,6 +176,15 @@ class UNet2DConditionModelMultiview(ModelBase):
         if load_weights_from_unet:
             model.load_state_dict(unet.state_dict(), strict=False)
         return model
+
+    def set_view_shard(self, shard):
+        """Spread the views of a scene over several GPUs (dualdiff_amd.parallel.ViewShard; None = off): the
+        model then runs on this rank's view-instances only and every `BasicMultiviewTransformerBlock`
+        fetches the neighbour views' K/V through `shard.exchange` (blocks.py:106-142)."""
+        for mod in self.modules():
+            if isinstance(mod, BasicMultiviewTransformerBlock):
+                mod.view_shard = shard
+        self.view_shard = shard
 
     # -- forward -----------------------------------------------------------------------------------
     def _timesteps(self, timestep, m, device):
@@ -299,3 +314,14 @@ class UNet2DConditionModelMultiview(ModelBase):
         if self.__dict__.get("_kv_bank") is not None:
             self.__dict__["_kv_bank"].drop()
         return O.conv3x3_small_cout(a, self.conv_out.packed, self.conv_out.bias, m, h, w)
+
+
+
+class UNet2DConditionModel(UNet2DConditionModelMultiview):
+    """The stock SD-v1.5 UNet (diffusers `UNet2DConditionModel`): same network without the neighbour-view
+    attention — `BasicTransformerBlock` instead of `BasicMultiviewTransformerBlock`, any number of views
+    (BASELINE configs[0]: one view, null text, no ControlNet).  It is what the reference loads from
+    `pretrained_model_name_or_path` and hands to `from_unet_2d_condition` (unet_2d_condition_multiview.py:
+    294-325); state-dict names are the diffusers ones, so `UNet2DConditionModelMultiview.
+    from_unet_2d_condition(plain_unet)` copies every shared weight."""
+    multiview = False

@@ -246,6 +246,25 @@ class BEVControlNetModel(ModelBase):
         ret.update(kwargs)
         return ret
 
+    def add_uncond_to_emb(self, prompt_embeds, N_cam, encoder_hidden_states_with_cam):
+        """Token-level CFG batch (:771-789): [uncond camera token | text | null box tokens] per prompt,
+        repeated over the N_cam views, in FRONT of the conditional tokens `(b*N_cam, L, 768)`.
+
+        The reference body cannot execute as written — it dereferences `self.controlnet` (an attribute only
+        the runner has) and feeds the 4-D `(b, n, L+1, 768)` result of `add_cam_states` to
+        `add_n_uncond_tokens`, which concatenates 3-D tokens on dim 1; no caller exists.  This is the evident
+        intent: the number of null box tokens makes both halves equally long."""
+        b = prompt_embeds.shape[0]
+        unc = self.add_cam_states(prompt_embeds, self._embed_camera(self.uncond_cam_param([b, 1])))   # b, 1, L+1, 768
+        unc = unc.reshape(b, unc.shape[2], unc.shape[3])
+        token_num = encoder_hidden_states_with_cam.shape[1] - unc.shape[1]
+        assert token_num >= 0
+        if token_num:
+            unc = self.bbox_embedder.add_n_uncond_tokens(unc, token_num)
+        unc = unc.to(encoder_hidden_states_with_cam.dtype)
+        unc = unc[:, None].expand(-1, N_cam, -1, -1).reshape(b * N_cam, unc.shape[1], unc.shape[2])
+        return torch.cat([unc, encoder_hidden_states_with_cam], dim=0)
+
     def prepare(self, cfg, **kwargs):
         self.bbox_embedder.prepare(cfg, **kwargs)
 
@@ -345,12 +364,19 @@ class BEVControlNetModel(ModelBase):
             drop_prefetched_kv(self, self.__dict__["_kv_stream"])
         if self.__dict__.get("_kv_bank") is not None:
             self.__dict__["_kv_bank"].drop()
+        # residual scale (:1041-1055): one factor, or one per residual (guess_mode: 13 log-spaced factors);
+        # either way it is the zero conv's epilogue `alpha`
+        nres = len(skips) + 1
+        scales = [float(conditioning_scale)] * nres if not isinstance(conditioning_scale, (list, tuple)) \
+            else [float(v) for v in conditioning_scale]
+        if len(scales) != nres:
+            raise ValueError("expected %d residual scales, got %d" % (nres, len(scales)))
         outs = []
         for i, ((s, sh, sw), zc) in enumerate(zip(skips, self.controlnet_down_blocks)):       # :1031-1054
             dst = out[i][0] if out is not None else None
-            outs.append((zc.run(s, alpha=conditioning_scale, out=dst, accumulate=accumulate), sh, sw))
+            outs.append((zc.run(s, alpha=scales[i], out=dst, accumulate=accumulate), sh, sw))
         dst = out[-1][0] if out is not None else None
-        outs.append((self.controlnet_mid_block.run(x, alpha=conditioning_scale, out=dst, accumulate=accumulate), h, w))
+        outs.append((self.controlnet_mid_block.run(x, alpha=scales[-1], out=dst, accumulate=accumulate), h, w))
         return outs
 
     def forward(
@@ -372,9 +398,12 @@ class BEVControlNetModel(ModelBase):
         **kwargs,
     ):
         use_aug_text = kwargs["use_aug_text"]          # required, as in the reference (:812)
-        if attention_mask is not None or class_labels is not None or timestep_cond is not None or guess_mode:
-            raise NotImplementedError("attention_mask / class_labels / timestep_cond / guess_mode are unused "
-                                      "by the DualDiff sampling path")
+        if attention_mask is not None or class_labels is not None or timestep_cond is not None:
+            raise NotImplementedError("attention_mask / class_labels / timestep_cond are unused by the DualDiff "
+                                      "sampling path")
+        if guess_mode:                                  # :1042-1050: 13 log-spaced factors 0.1 ... 1.0
+            conditioning_scale = (torch.logspace(-1, 0, len(self.controlnet_down_blocks) + 1)
+                                  * conditioning_scale).tolist()
         if not sample.is_cuda:
             raise RuntimeError("dualdiff_amd runs on the GPU only; got a %s tensor" % sample.device)
         dt = self.dtype

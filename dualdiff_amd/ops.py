@@ -297,7 +297,7 @@ def _rows2d(t):
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
          out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
-         ln_stats=False, head_major=None):
+         ln_stats=False, head_major=None, ln_direct=None):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
     head_major = (D, scaled_planes, scale): the result comes back as (n / D, rows, D) — one contiguous
     [rows][D] plane per head of a fused Q|K|V projection, the first `scaled_planes` planes multiplied by
@@ -305,6 +305,10 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     out_f32: the result is stored as fp32 (attention logits that feed a softmax).
     ln_stats: the epilogue also leaves per-row partial sums of the output (n % 32 == 0) as `out._ln_stats`;
     a later gemm(out, ..., ln=...) picks them up instead of recomputing the row statistics.
+
+    ln_direct = (gamma, beta, eps): LayerNorm PROLOGUE of the row-panel kernels — `a` is the un-normalised
+    input, every row panel is normalised in LDS (dd_layernorm's arithmetic) before it is multiplied; K in
+    {320, 640, 1280}, n a multiple of the family's column slice (rowpanel_ok()).
 
     ln = (colsum_f32, bias_f32, eps): LayerNorm fold — `a` is the UN-normalised input, `w` the
     gamma-scaled weight; the kernel computes the row statistics itself (include/dualdiff_hip.h)."""
@@ -365,6 +369,14 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
             if tuple(stats_in.shape) != (rows, k // 32, 2) or stats_in.dtype != torch.float32:
                 raise ValueError("stale LayerNorm statistics attached to the input")
             d.ln_stats_in = stats_in.data_ptr()
+    if ln_direct is not None:
+        if ln is not None or a2 is not None:
+            raise ValueError("gemm(ln_direct=...) takes a single source and excludes the algebraic fold")
+        g_, b_, eps_ = ln_direct
+        _need_gpu(g_, b_)
+        if g_.dtype != a.dtype or b_.dtype != a.dtype or g_.numel() != k or b_.numel() != k:
+            raise ValueError("ln_direct gamma / beta must be %s vectors of %d entries" % (a.dtype, k))
+        d.ln_gamma, d.ln_beta, d.ln_eps = g_.data_ptr(), b_.data_ptr(), float(eps_)
     stats_out = None
     if ln_stats:
         if n % 32 or epilogue == DD_EPI_GEGLU or out_f32:
@@ -375,7 +387,9 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
                                       + (("f32",) if out_f32 else ()) + (("so",) if ln_stats else ())
                                       + (("si",) if stats_in is not None else ())
-                                      + (("hm", head_major[0]) if head_major is not None else ()),
+                                      + (("hm", head_major[0]) if head_major is not None else ())
+                                      + (("lnd",) if ln_direct is not None else ())
+                                      + (("res",) if res is not None else ()) + (("acc",) if accumulate else ()),
                                       (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
@@ -464,10 +478,13 @@ def groupnorm(x, gamma, beta, m, hw, groups, eps, silu, x2=None, out=None):
         out = torch.empty((m * hw, c1 + c2), dtype=x.dtype, device=x.device)
     need = lib.dd_groupnorm_workspace_bytes(m, groups)
     ws = workspace(need, x.device, "gn")
+    e0 = _TIMER.start() if _TIMER is not None else None
     rc = lib.dd_groupnorm_nhwc(_ptr(x), c1, _ptr(x2), c2, _ptr(gamma), _ptr(beta), _ptr(out),
                                m, hw, groups, eps, int(silu), _dt(x), _ptr(ws), ws.numel() * 4,
                                _stream())
     _native.check(rc, "groupnorm")
+    if e0 is not None:      # HBM-bound: each element read once and written once
+        _TIMER.stop(e0, "dd_groupnorm (gn_fused | gn_stats + gn_apply)", 0.0, 4.0 * out.numel())
     return out
 
 
@@ -479,9 +496,12 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
         raise ValueError("layernorm input must be contiguous")
     if out is None:
         out = torch.empty_like(x)
+    e0 = _TIMER.start() if _TIMER is not None else None
     rc = lib.dd_layernorm(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1],
                           eps, _dt(x), _stream())
     _native.check(rc, "layernorm")
+    if e0 is not None:
+        _TIMER.stop(e0, "dd_layernorm", 0.0, 4.0 * out.numel())
     return out
 
 
@@ -500,7 +520,14 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     d = AttnDesc()
 
     def operand(t, l):
-        """-> (ptr, ld, batch stride, head stride) for a row-major 2-D view or a head-major 3-D tensor."""
+        """-> (ptr, ld, batch stride, head stride) for a row-major 2-D view, a head-major 3-D tensor
+        (heads, rows, d) or a batch-major 4-D tensor (batches, heads, l, d) with contiguous [l][d] blocks (the
+        K/V layout of the view-sharded neighbour attention: whole instances are contiguous messages)."""
+        if t.dim() == 4:
+            if t.shape[1] != heads or t.shape[2] != l or t.shape[3] != head_dim or t.stride(3) != 1 \
+                    or t.stride(2) != head_dim:
+                raise ValueError("batch-major operand must be (batches, heads, l, head_dim) with contiguous blocks")
+            return t.data_ptr(), head_dim, t.stride(0), t.stride(1)
         if t.dim() == 3:
             if t.shape[0] != heads or t.shape[2] != head_dim or t.stride(2) != 1 or t.stride(1) != head_dim:
                 raise ValueError("head-major operand must be (heads, rows, head_dim) with contiguous planes")
@@ -538,8 +565,11 @@ def add(a, b, c=None, out=None):
     _need_gpu(a, b, c, out)
     if out is None:
         out = torch.empty_like(a)
+    e0 = _TIMER.start() if _TIMER is not None else None
     rc = lib.dd_add(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _dt(a), _stream())
     _native.check(rc, "add")
+    if e0 is not None:
+        _TIMER.stop(e0, "dd_add", 0.0, 2.0 * a.numel() * (3 + (1 if c is not None else 0)))
     return out
 
 
@@ -695,6 +725,13 @@ def fourier_embed(x, freqs, include_input=True):
     _native.check(lib.dd_fourier_embed(_ptr(x), _ptr(out), rows, dims, arr, nf, int(include_input), code, code,
                                        _stream()), "fourier_embed")
     return out
+
+
+def rowpanel_ok(k, n):
+    """Shapes the row-panel GEMM family (tiles 41 / 42, LayerNorm prologue) covers: K = C of a transformer
+    level and n a whole number of its column slices (4 waves x 5 or 2 MFMA blocks of 16)."""
+    bn = {320: 320, 640: 128, 1280: 128}.get(int(k))
+    return bn is not None and int(n) % bn == 0
 
 
 def gemm_kernel_name(rows, n, k, dtype=torch.bfloat16, conv=False, cin=0, hw=(0, 0)):

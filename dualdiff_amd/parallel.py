@@ -66,3 +66,182 @@ def cfg_all_gather(eps_half, group=None):
     out = [torch.empty_like(eps_half), torch.empty_like(eps_half)]
     dist.all_gather(out, eps_half, group=group)
     return torch.stack(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# View split: the 6 views of ONE scene (per CFG half) over several GPUs.
+#
+# Everything in the denoising step is per view-instance except
+#   (i)  attn4 of `BasicMultiviewTransformerBlock` (reference blocks.py:106-142,190-222): view v attends to
+#        the K/V of its neighbours pair[v] — in each of the 16 UNet transformer blocks; and
+#   (ii) the CFG combine (pipeline_bev_controlnet.py:487-490), once per step.
+# Ranks are laid out as  rank = shard * halves + half : with `cfg_split` (even world) the two ranks
+# {2s, 2s+1} hold the unconditional / conditional half of the SAME views (the pair groups of the CFG
+# split exchange the noise prediction), and ranks of equal parity form a half group inside which the
+# neighbour K/V travel.  Without it (odd world) every rank holds both halves of its views.
+#
+# What travels is the PROJECTED K/V of whole view-instances, head-major ([2*heads][l][d] per instance and
+# CFG half — contiguous, so a message is one zero-copy slice of the block's K/V buffer), straight to the
+# ranks that need them: point-to-point isend / irecv, never a ring collective.  Per view and block:
+# 2 * l * C * 2 B = 1.8 MB (28x50, C = 320), 0.9 MB (14x25, 640), 0.47 MB (7x13, 1280), 0.14 MB (4x7).
+# ------------------------------------------------------------------------------------------------
+def split_views(n_cam, shards):
+    """Contiguous balanced view ranges: [[views of shard 0], ...] (first shards take the remainder)."""
+    if not (1 <= shards <= n_cam):
+        raise ValueError("cannot split %d views over %d shards" % (n_cam, shards))
+    return [list(range(*shard_scenes(n_cam, s, shards))) for s in range(shards)]
+
+
+class ViewSplitPlan:
+    """Static plan of one rank: which views it owns, which neighbour views it needs from whom, which of its
+    views others need.  Pure Python / deterministic on every rank (no communication)."""
+
+    def __init__(self, world, rank, view_pair, cfg_split=None):
+        self.world, self.rank = world, rank
+        self.pair = {int(k): [int(x) for x in v] for k, v in view_pair.items()}
+        self.n_cam = len(self.pair)
+        if cfg_split is None:
+            cfg_split = world % 2 == 0
+        if cfg_split and world % 2:
+            raise ValueError("cfg_split needs an even world size")
+        self.cfg_split = bool(cfg_split)
+        self.halves = 2 if self.cfg_split else 1          # CFG halves spread over ranks
+        self.shards = world // self.halves
+        self.shard, self.half = rank // self.halves, (rank % self.halves if self.cfg_split else None)
+        self.views_of = split_views(self.n_cam, self.shards)
+        self.local = self.views_of[self.shard]
+        self.owner = {v: s for s, vs in enumerate(self.views_of) for v in vs}
+        self.remote = self._needs(self.shard)
+        # shard -> views (send: mine that they need; recv: theirs that I need), each in sorted view order
+        self.send = {s: [v for v in self._needs(s) if self.owner[v] == self.shard]
+                     for s in range(self.shards) if s != self.shard}
+        self.recv = {s: [v for v in self.remote if self.owner[v] == s] for s in range(self.shards) if s != self.shard}
+        self.send = {s: v for s, v in self.send.items() if v}
+        self.recv = {s: v for s, v in self.recv.items() if v}
+
+    def _needs(self, shard):
+        mine = set(self.views_of[shard])
+        return sorted({u for v in self.views_of[shard] for u in self.pair[v]} - mine)
+
+    def rank_of(self, shard):
+        """Global rank of `shard` inside this rank's half group."""
+        return shard * self.halves + (self.half or 0)
+
+    @property
+    def n_slots(self):
+        return len(self.local) + len(self.remote)
+
+    def slot(self, view):
+        """Slot of `view` in this rank's K/V buffer: local views first (in order), then the remote ones."""
+        if view in self.local:
+            return self.local.index(view)
+        return len(self.local) + self.remote.index(view)
+
+    def kv_maps(self, nb):
+        """One int list per neighbour position j: local instance (bi, vi) [index bi * n_local + vi] -> batch
+        index of the K/V of pair[view][j] in the slot-major buffer (slot * nb + bi)."""
+        depth = max(len(v) for v in self.pair.values())
+        nloc = len(self.local)
+        return [[self.slot(self.pair[self.local[i % nloc]][j]) * nb + i // nloc for i in range(nb * nloc)]
+                for j in range(depth)]
+
+    def cfg_partner_group_ranks(self):
+        """Ranks [uncond, cond] that hold the two CFG halves of this rank's views (cfg_split only)."""
+        return [self.shard * 2, self.shard * 2 + 1] if self.cfg_split else None
+
+    def message_bytes(self, n_tokens, channels, nb=1, elem=2):
+        """Bytes this rank sends / receives per transformer block at a level (documentation)."""
+        one = 2 * n_tokens * channels * elem * nb
+        return sum(len(v) for v in self.send.values()) * one, len(self.remote) * one
+
+
+class HaloExchange:
+    """Moves neighbour-view K/V between the ranks of a half group with point-to-point messages.
+    `kv` is the slot-major buffer (n_slots, nb, 2*heads, l, d): slots [0, n_local) hold this rank's views
+    (already written), the exchange fills the remote slots.  RCCL backend: device tensors go out as they
+    are (batch_isend_irecv on the backend's stream, the current stream waits — no host sync).  gloo backend
+    (CPU tests / the shared-GPU plumbing mode): device tensors are staged through host memory."""
+
+    def __init__(self, plan, group=None):
+        self.plan, self.group = plan, group
+
+    def __call__(self, kv):
+        pl = self.plan
+        if not pl.send and not pl.recv:
+            return kv
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("HaloExchange needs an initialised process group")
+        staged = kv.is_cuda and dist.get_backend(self.group) == "gloo"
+        ops, holds, landing = [], [], []
+        for s in sorted(set(pl.send) | set(pl.recv)):
+            peer = pl.rank_of(s)
+            for v in pl.send.get(s, ()):
+                t = kv[pl.slot(v)]
+                t = t.cpu() if staged else t
+                holds.append(t)
+                ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+            for v in pl.recv.get(s, ()):
+                dst = kv[pl.slot(v)]
+                t = torch.empty(dst.shape, dtype=dst.dtype) if staged else dst
+                landing.append((dst, t))
+                ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if staged:
+            for dst, t in landing:
+                dst.copy_(t)
+        return kv
+
+
+def view_split_groups(world, cfg_split=True):
+    """(half groups, pair groups): process groups of ranks with equal parity (neighbour K/V exchange) and of
+    the rank pairs {2s, 2s+1} (CFG exchange).  Collective: EVERY rank must call it, in the same order.
+    Without cfg_split there is one half group (all ranks) and no pair group."""
+    if not cfg_split:
+        return [dist.new_group(list(range(world)))], []
+    halves = [dist.new_group(list(range(h, world, 2))) for h in (0, 1)]
+    return halves, cfg_pair_groups(world)
+
+
+class ViewShard:
+    """What a view-sharded model needs at run time: the static plan, the exchange callable (HaloExchange,
+    or an in-process stand-in for tests) and cached device-side kv_batch_maps.  Installed on every
+    `BasicMultiviewTransformerBlock` by `UNet2DConditionModelMultiview.set_view_shard`."""
+
+    def __init__(self, plan, exchange=None):
+        self.plan = plan
+        self.exchange = exchange if exchange is not None else HaloExchange(plan)
+        self._maps = {}
+
+    @property
+    def n_local(self):
+        return len(self.plan.local)
+
+    def maps(self, nb, device):
+        key = (nb, str(device))
+        if key not in self._maps:
+            self._maps[key] = [torch.tensor(m, dtype=torch.int32, device=device) for m in self.plan.kv_maps(nb)]
+        return self._maps[key]
+
+    # ---- input slicing (sampler level) -------------------------------------------------------
+    def take_views(self, t, dim, n_cam=None):
+        """Keeps this rank's views along `dim` (size n_cam); tensors whose `dim` is 1 are shared by all views."""
+        n_cam = n_cam or self.plan.n_cam
+        if t.shape[dim] == 1:
+            return t
+        if t.shape[dim] != n_cam:
+            raise ValueError("dim %d of %s is neither 1 nor n_cam = %d" % (dim, tuple(t.shape), n_cam))
+        lo, hi = self.plan.local[0], self.plan.local[-1] + 1
+        return t.narrow(dim, lo, hi - lo)
+
+    def take_panorama(self, cond):
+        """(b, c, h, n_cam * w) panorama (views side by side, map_embedder.py:116-125) -> this rank's columns."""
+        w = cond.shape[-1] // self.plan.n_cam
+        lo, hi = self.plan.local[0], self.plan.local[-1] + 1
+        return cond[..., lo * w:hi * w]
+
+    def take_instances(self, t, nb):
+        """(nb * n_cam, ...) view-instances, scene-major -> (nb * n_local, ...) of this rank's views."""
+        n = self.plan.n_cam
+        lo, hi = self.plan.local[0], self.plan.local[-1] + 1
+        return t.reshape(nb, n, *t.shape[1:])[:, lo:hi].reshape(nb * (hi - lo), *t.shape[1:])

@@ -140,6 +140,13 @@ typedef struct dd_gemm_desc {
   int32_t out_headmajor_d;
   int32_t hm_scaled_planes;
   float hm_scale;
+  /* Direct LayerNorm prologue (dense mode, K in {320, 640, 1280}, row-panel tiles 41 / 42 only): `a` holds the
+   * UN-normalised rows; every row panel is normalised in LDS — two-pass fp32 mean / variance over the K columns,
+   * (x - mean) * rstd * ln_gamma + ln_beta rounded to the storage type, i.e. dd_layernorm's arithmetic — before
+   * it is multiplied.  Replaces LayerNorm + Linear of norm1 -> to_q/k/v, norm2 -> to_q, norm4 -> attn4 q/k/v
+   * (networks/blocks.py:150-222) without a LayerNorm launch.  ln_gamma / ln_beta: T [k]; eps in ln_eps. */
+  const void* ln_gamma;    /* NULL = no prologue */
+  const void* ln_beta;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);

@@ -320,7 +320,7 @@ class BEVControlNetModel(D.ModelMixin):
         return e.reshape(b, n, -1)
 
     def forward(self, sample, timestep, camera_param, bboxes_3d_data, encoder_hidden_states,
-                controlnet_cond, conditioning_scale=1.0):
+                controlnet_cond, conditioning_scale=1.0, guess_mode=False):
         b, n_cam = camera_param.shape[:2]
         cam_tok = self.cam2token(self._embed_camera(camera_param))                      # :349
         txt = encoder_hidden_states[:, None].expand(-1, n_cam, -1, -1)                    # :354
@@ -367,8 +367,15 @@ class BEVControlNetModel(D.ModelMixin):
                 x, res = blk(hidden_states=x, temb=emb)
             skips += res
         x = self.mid_block(x, emb, encoder_hidden_states=blk_ctx)
-        down = [zc(s) * conditioning_scale for s, zc in zip(skips, self.controlnet_down_blocks)]   # :1031-1054
-        mid = self.controlnet_mid_block(x) * conditioning_scale                           # :1039,:1055
+        down = [zc(s) for s, zc in zip(skips, self.controlnet_down_blocks)]              # :1031-1039
+        mid = self.controlnet_mid_block(x)
+        if guess_mode:                                                                    # :1042-1050
+            scales = torch.logspace(-1, 0, len(down) + 1) * conditioning_scale            # 0.1 ... 1.0
+            down = [d * sc for d, sc in zip(down, scales)]
+            mid = mid * scales[-1]
+        else:                                                                             # :1051-1055
+            down = [d * conditioning_scale for d in down]
+            mid = mid * conditioning_scale
         return down, mid, full_ctx                                                        # :1066-1076
 
 

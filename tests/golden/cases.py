@@ -189,3 +189,41 @@ def ors_inputs():
         Ks.append(K)
         Rts.append(Rt)
     return occ, Ks, Rts
+
+
+# ---------------------------------------------------------------- full dual-branch step / trajectory ----
+# The config-2 step at full SD-v1.5 widths (b = 1 scene: 12 view-instances, 2 ControlNet branches, SFA on,
+# CFG 2.0) with short token lists (9 text tokens, 5 boxes) so that the CPU oracle stays affordable.  Same
+# seeds as tests/test_model_gpu.py's dual-branch test.  Used by tests/golden/mint_trajectory.py (oracle
+# trajectory -> trajectory_ddim50.npz) and tests/test_parity_r02_gpu.py (HIP path vs that fixture).
+STEP_NBOX, STEP_LTXT = 5, 9
+SEED_STEP_UNET, SEED_STEP_CNET_BG, SEED_STEP_CNET_FG, SEED_STEP_LAT = 21, 31, 32, 77
+TRAJ_CHECKPOINTS = (1, 2, 3, 5, 10, 20, 30, 40, 50)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32) if t.is_floating_point() else t
+
+
+def step_inputs(b=2):
+    """(uncond, cond) rows of every conditioning input, rounded to bf16-representable values."""
+    g = torch.Generator().manual_seed(7)
+    return {
+        "sample": bf16_round(seeded_tensor((b, N_CAM, 4, H, W), 11)),
+        "timestep": torch.tensor([981.0, 41.0][:b]),
+        "camera_param": bf16_round(seeded_tensor((b, N_CAM, 3, 7), 12)),
+        "text": bf16_round(seeded_tensor((b, STEP_LTXT, 768), 13)),
+        "boxes_bg": {"bboxes": bf16_round((torch.rand((b, N_CAM, STEP_NBOX, 8, 3), generator=g) - 0.5) * 20.0),
+                     "classes": torch.randint(0, 10, (b, N_CAM, STEP_NBOX), generator=g),
+                     "masks": torch.rand((b, N_CAM, STEP_NBOX), generator=g) > 0.3},
+        "boxes_fg": {"bboxes": bf16_round((torch.rand((b, 1, STEP_NBOX, 8, 3), generator=g) - 0.5) * 20.0),
+                     "classes": torch.randint(0, 10, (b, 1, STEP_NBOX), generator=g),
+                     "masks": torch.rand((b, 1, STEP_NBOX), generator=g) > 0.3},
+        "cond_bg": bf16_round(torch.rand((b, 3, 224, 2400), generator=g)),
+        "cond_fg": bf16_round(torch.randint(0, 18, (b * N_CAM, 320, H, W), generator=g).float() / 17.0),
+    }
+
+
+def step_latents():
+    """(1, 6, 4, 28, 50): one draw replicated over the 6 views (pipeline_bev_controlnet.py:345)."""
+    return bf16_round(seeded_tensor((1, 4, H, W), SEED_STEP_LAT))[:, None].expand(-1, N_CAM, -1, -1, -1).contiguous()

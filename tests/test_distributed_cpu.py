@@ -3,6 +3,8 @@ only bookkeeping collectives: max-over-ranks time, result gather)."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -91,3 +93,110 @@ def test_cfg_split_exchange_gloo():
         assert shape == (2, 6, 4, 2, 3)
         assert (u, c) == (10.0 * scene, 10.0 * scene + 1.0)
         assert g == u + 2.0 * (c - u)
+
+
+# ------------------------------------------------------------------------- view split ----
+PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+
+
+def _attn_ref(q, k, v):
+    """(heads, l, d) x (heads, lk, d): plain softmax attention, one instance at a time (so that sharded and
+    unsharded runs execute identical arithmetic per instance -> bit-for-bit comparable)."""
+    s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    return s.softmax(dim=-1) @ v
+
+
+def _full_case(nb, heads=2, l=5, d=8, n_cam=6):
+    g = torch.Generator().manual_seed(123)
+    q = torch.randn((nb, n_cam, heads, l, d), generator=g)
+    kv = torch.randn((n_cam, nb, 2 * heads, l, d), generator=g)       # slot-major like the block's buffer
+    out = torch.zeros((nb, n_cam, heads, l, d))
+    for bi in range(nb):
+        for v in range(n_cam):
+            for u in PAIR[v]:                                          # blocks.py:203-217: sum over the neighbours
+                out[bi, v] += _attn_ref(q[bi, v], kv[u, bi, :heads], kv[u, bi, heads:])
+    return q, kv, out
+
+
+def _view_worker(rank, world, port, cfg_split, out):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from dualdiff_amd.parallel import HaloExchange, ViewShard, ViewSplitPlan, view_split_groups
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    halves, pairs = view_split_groups(world, cfg_split)
+    plan = ViewSplitPlan(world, rank, PAIR, cfg_split=cfg_split)
+    group = halves[plan.half or 0]
+    shard = ViewShard(plan, HaloExchange(plan, group))
+    heads = 2
+    nb_full = 2                                   # two CFG halves of one scene
+    q, kv_full, ref = _full_case(nb_full, heads=heads)
+    # this rank's CFG halves: one (cfg_split) or both
+    bis = [plan.half] if cfg_split else list(range(nb_full))
+    nb, nloc = len(bis), len(plan.local)
+    kv = torch.full((plan.n_slots, nb) + tuple(kv_full.shape[2:]), float("nan"))
+    for si, v in enumerate(plan.local):
+        kv[si] = kv_full[v][bis]
+    shard.exchange(kv)
+    ok_kv = all(torch.equal(kv[plan.slot(v)], kv_full[v][bis]) for v in plan.remote) and not torch.isnan(kv).any()
+    maps = shard.maps(nb, "cpu")
+    flat = kv.reshape(plan.n_slots * nb, *kv.shape[2:])
+    ok_out = True
+    for i in range(nb * nloc):                    # instance (bi, vi) = i // nloc, i % nloc
+        bi, vi = i // nloc, i % nloc
+        acc = torch.zeros_like(ref[0, 0])
+        for mp in maps:
+            src = flat[int(mp[i])]
+            acc += _attn_ref(q[bis[bi], plan.local[vi]], src[:heads], src[heads:])
+        ok_out = ok_out and torch.equal(acc, ref[bis[bi], plan.local[vi]])
+    out.put((rank, plan.half, plan.local, bool(ok_kv), bool(ok_out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cfg_split", [(2, False), (3, False), (4, True), (6, False)])
+def test_view_split_halo_exchange_gloo(world, cfg_split):
+    """Views of a scene sharded over `world` ranks: after the point-to-point K/V halo exchange every rank's
+    buffer holds exactly the neighbour views' K/V (bit for bit), and the neighbour-view attention computed
+    from it equals the single-process result bit for bit — world 2 / 3 / 6 (both CFG halves per rank) and
+    4 (CFG halves x 2 view shards, exchange inside the half groups)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_view_worker, args=(r, world, port, cfg_split, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    covered = {}
+    for rank, half, local, ok_kv, ok_out in got:
+        assert ok_kv and ok_out, (rank, half, local, ok_kv, ok_out)
+        covered.setdefault(half, []).extend(local)
+    for half, views in covered.items():
+        assert sorted(views) == list(range(6)), (half, views)
+
+
+def test_view_split_plan_properties():
+    """Every layout: each view owned once per half group, send / recv lists mirror each other, the 8-GPU
+    layout is the SURVEY's 4 x 2 + 4 x 1 instances."""
+    from dualdiff_amd.parallel import ViewSplitPlan
+    for world in (1, 2, 3, 4, 5, 6, 8, 12):
+        plans = [ViewSplitPlan(world, r, PAIR) for r in range(world)]
+        for p in plans:
+            for s, views in p.send.items():
+                peer = plans[p.rank_of(s)]
+                assert peer.recv[p.shard] == views and (peer.half == p.half)
+            for v in p.remote:
+                assert v not in p.local and any(v in PAIR[u] for u in p.local)
+            for j, mp_ in enumerate(p.kv_maps(1)):
+                for vi, slot in enumerate(mp_):
+                    want = PAIR[p.local[vi]][j]
+                    assert (p.local + p.remote)[slot] == want
+    p8 = [ViewSplitPlan(8, r, PAIR) for r in range(8)]
+    assert sorted(len(p.local) for p in p8) == [1, 1, 1, 1, 2, 2, 2, 2]
+    assert p8[0].message_bytes(1400, 320) == (2 * 2 * 1400 * 320 * 2, 2 * 2 * 1400 * 320 * 2)

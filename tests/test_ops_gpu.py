@@ -64,6 +64,69 @@ def test_gemm_tiles(ops, dtype, tile, rows, n, k):
     check(y, L.linear_ref(a, w, b), dtype, "gemm tile%d %dx%dx%d" % (tile, rows, n, k))
 
 
+RP_SHAPES = [(16800, 320, 320), (1400 * 3 + 5, 960, 320), (4200, 640, 640), (350 * 2 + 9, 1920, 640),
+             (1092, 1280, 1280), (336, 3840, 1280), (28, 1280, 1280), (12, 1280, 320)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [41, 42])
+@pytest.mark.parametrize("rows,n,k", RP_SHAPES)
+def test_gemm_rowpanel(ops, dtype, tile, rows, n, k):
+    """Row-panel family (weights in registers, rows streamed as full-K panels): plain, bias + residual +
+    alpha, accumulate into a strided output, head-major planes with the Q scale — ragged row counts included."""
+    if tile == 42 and k == 1280:
+        pytest.skip("32-row panels of K = 1280 do not fit LDS")
+    a = rnd((rows, k), dtype, 1)
+    w = rnd((n, k), dtype, 2, 0.05)
+    b = rnd((n,), dtype, 3)
+    res = rnd((rows, n), dtype, 4)
+    check(ops.gemm(a, w, tile=tile), L.linear_ref(a, w), dtype, "rp%d plain %dx%dx%d" % (tile, rows, n, k))
+    y = ops.gemm(a, w, b, res=res, alpha=0.5, tile=tile)
+    check(y, L.linear_ref(a, w, b, res=res, alpha=0.5), dtype, "rp%d bias+res+alpha" % tile)
+    buf = rnd((rows, n + 64), dtype, 6)
+    ref = buf.float().cpu().clone()
+    ref[:, 32:32 + n] += L.linear_ref(a, w, b)
+    ops.gemm(a, w, b, out=buf[:, 32:32 + n], accumulate=True, tile=tile)
+    check(buf, ref, dtype, "rp%d accumulate strided" % tile, 2.0)
+    hd = {320: 40, 640: 80, 1280: 160}[k]
+    if n % hd == 0:
+        planes = n // hd
+        hm = ops.gemm(a, w, tile=tile, head_major=(hd, planes // 3 if planes >= 3 else planes, 0.25))
+        full = L.linear_ref(a, w)
+        nsc = (planes // 3 if planes >= 3 else planes) * hd
+        full[:, :nsc] *= 0.25
+        want = full.reshape(rows, planes, hd).permute(1, 0, 2).contiguous()
+        check(hm, want, dtype, "rp%d head-major" % tile)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 41, 42])
+@pytest.mark.parametrize("rows,n,k", [(16800, 960, 320), (1400 + 3, 320, 320), (4200, 1920, 640), (1092, 1280, 1280),
+                                      (336, 3840, 1280)])
+def test_gemm_rowpanel_layernorm_prologue(ops, dtype, tile, rows, n, k):
+    """LayerNorm prologue of the row-panel GEMM == LayerNorm kernel followed by the GEMM (the LayerNorm output
+    rounded to the storage type in both), with a residual and as head-major Q|K|V planes."""
+    if tile == 42 and k == 1280:
+        pytest.skip("32-row panels of K = 1280 do not fit LDS")
+    x = rnd((rows, k), dtype, 1) * 3 + 1
+    g = rnd((k,), dtype, 2) + 1.0
+    be = rnd((k,), dtype, 3)
+    w = rnd((n, k), dtype, 4, 0.05)
+    xn = L.layernorm_ref(x, g, be).to(dtype)                     # the reference rounds LN's output too
+    y = ops.gemm(x, w, tile=tile, ln_direct=(g, be, 1e-5))
+    check(y, L.linear_ref(xn, w), dtype, "rp%d LN prologue %dx%dx%d" % (tile, rows, n, k), 2.0)
+    if n == k:
+        res = rnd((rows, n), dtype, 5)
+        y = ops.gemm(x, w, res=res, tile=tile, ln_direct=(g, be, 1e-5))
+        check(y, L.linear_ref(xn, w, res=res), dtype, "rp%d LN prologue + res" % tile, 2.0)
+    hd = {320: 40, 640: 80, 1280: 160}[k]
+    planes = n // hd
+    hm = ops.gemm(x, w, tile=tile, ln_direct=(g, be, 1e-5), head_major=(hd, 8, 0.3))
+    full = L.linear_ref(xn, w)
+    full[:, :8 * hd] *= 0.3
+    check(hm, full.reshape(rows, planes, hd).permute(1, 0, 2).contiguous(), dtype, "rp%d LN + head-major" % tile, 2.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogue_full(ops, dtype):
     rows, n, k = 12 * 91, 640, 1280
