@@ -107,10 +107,8 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
                             accumulate=j > 0, q_prescaled=True)
         return o, len(maps)
 
-    def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
-        h = self._attn(self.attn1, self.norm1, h, batch, l)
-        h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
-        # ---- neighbour-view attention ------------------------------------------------------
+    def _cross_view(self, h, batch, l):
+        """norm4 -> attn4 over the neighbour views -> connector -> + h (blocks.py:190-222)."""
         a = self.attn4
         c = a.inner_dim
         if self.view_shard is not None:
@@ -128,12 +126,16 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             nb = len(maps)
         if self.fold_connector:
             w, b = self._folded_out(nb)
-            h = O.gemm(o, w, b, res=h, ln_stats=want_ln_stats())        # feeds norm3
-        else:
-            if "_pk_bias_nb" not in a.__dict__ or a.__dict__["_pk_bias_nb"][0] != nb:
-                a.__dict__["_pk_bias_nb"] = (nb, (a.to_out[0].bias.detach().float() * nb).to(a.to_out[0].bias.dtype))
-            y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
-            h = self.connector.run(y, res=h, ln_stats=want_ln_stats())
+            return O.gemm(o, w, b, res=h, ln_stats=want_ln_stats())        # feeds norm3
+        if "_pk_bias_nb" not in a.__dict__ or a.__dict__["_pk_bias_nb"][0] != nb:
+            a.__dict__["_pk_bias_nb"] = (nb, (a.to_out[0].bias.detach().float() * nb).to(a.to_out[0].bias.dtype))
+        y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
+        return self.connector.run(y, res=h, ln_stats=want_ln_stats())
+
+    def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
+        h = self._attn(self.attn1, self.norm1, h, batch, l)
+        h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
+        h = self._cross_view(h, batch, l)
         # ---- feed-forward ------------------------------------------------------------------
         if defer_ff_out:
             return self.ff.run(h, norm=self.norm3, defer_out=True), h

@@ -26,17 +26,20 @@ class ControlNetConditioningEmbedding(nn.Module):
             self.blocks.append(Conv3x3(ci, co, stride=2))
         self.conv_out = Conv3x3(block_out_channels[-1], conditioning_embedding_channels)
 
-    def run(self, conditioning):
-        """(b, c, h, 6*w) NCHW panorama -> ((b*6*h'*w'), C) NHWC rows, b*6, h', w'."""
+    def run(self, conditioning, n_views=6):
+        """(b, c, h, n_views*w) NCHW panorama -> ((b*n_views*h'*w'), C) NHWC rows, b*n_views, h', w'.
+        The reference hard-codes 6 views (map_embedder.py:116-125); a view-sharded rank passes the columns of
+        its own views only."""
         b, c, h, pw = conditioning.shape
-        w = pw // 6
+        nv = int(n_views)
+        w = pw // nv
         dt = self.conv_in.weight.dtype
         # view split (map_embedder.py:116-125) + NHWC + channel pad to 8 in one boundary copy
-        x = conditioning.to(dt).reshape(b, c, h, 6, w).permute(0, 3, 2, 4, 1)       # b, view, h, w, c
-        xp = x.new_zeros((b, 6, h, w, self.conv_in.cin_pad))
+        x = conditioning.to(dt).reshape(b, c, h, nv, w).permute(0, 3, 2, 4, 1)      # b, view, h, w, c
+        xp = x.new_zeros((b, nv, h, w, self.conv_in.cin_pad))
         xp[..., :c] = x
-        x = xp.reshape(b * 6 * h * w, self.conv_in.cin_pad)
-        m = b * 6
+        x = xp.reshape(b * nv * h * w, self.conv_in.cin_pad)
+        m = b * nv
         x = self.conv_in.run(x, m, h, w, epilogue=O.DD_EPI_SILU)
         for blk in self.blocks:
             x = blk.run(x, m, h, w, epilogue=O.DD_EPI_SILU)

@@ -36,6 +36,7 @@ class UNet2DConditionModelMultiview(ModelBase):
     # True: `BasicMultiviewTransformerBlock` (attn4 + connector) in every transformer; the plain SD-v1.5
     # subclass below turns it off
     multiview = True
+    video = False      # True: VideoMultiviewTransformerBlock (UNet2DConditionModelMultiviewVideo below)
     # Side-stream projection of the cross-attention K/V (layers.prefetch_cross_kv).  Measured on MI355X
     # (config 2, graph replay): 66.0 steps/s off vs 62.4 on — the extra stream's small GEMMs delay the
     # main chain more than they shorten it — so it is off; DD_PREFETCH_KV=1 turns it on.
@@ -111,6 +112,11 @@ class UNet2DConditionModelMultiview(ModelBase):
             blk_kw = dict(neighboring_view_pair=pair, neighboring_attn_type=neighboring_attn_type,
                           zero_module_type=zero_module_type)
             bcls = BasicMultiviewTransformerBlock
+            nf = other_diffusers_config.get("n_frames")
+            if self.video:                                   # extension: ST-Attn + temporal attention per block
+                from .video_blocks import VideoMultiviewTransformerBlock
+                bcls = VideoMultiviewTransformerBlock
+                blk_kw["n_frames"] = int(nf or 1)
         else:
             blk_kw, bcls = {}, BasicTransformerBlock
 
@@ -325,3 +331,20 @@ class UNet2DConditionModel(UNet2DConditionModelMultiview):
     294-325); state-dict names are the diffusers ones, so `UNet2DConditionModelMultiview.
     from_unet_2d_condition(plain_unet)` copies every shared weight."""
     multiview = False
+
+
+
+class UNet2DConditionModelMultiviewVideo(UNet2DConditionModelMultiview):
+    """EXTENSION (BASELINE configs[3]; no reference semantics — see networks/video_blocks.py): the multiview
+    UNet with ST-Attn and temporal attention in every transformer block.  `n_frames` (config key) frames per
+    scene; instances are ordered scene-major, then frame, then view.  State dict = the image model's keys plus
+    `...transformer_blocks.0.{norm_temp, attn_temp.*}`, so `load_state_dict(image_sd, strict=False)` starts a
+    video model from an image checkpoint (attn_temp.to_out zero-initialised by the trainer)."""
+    video = True
+
+    def set_n_frames(self, n_frames):
+        from .video_blocks import VideoMultiviewTransformerBlock
+        for mod in self.modules():
+            if isinstance(mod, VideoMultiviewTransformerBlock):
+                mod.n_frames = int(n_frames)
+        self.config["n_frames"] = int(n_frames)

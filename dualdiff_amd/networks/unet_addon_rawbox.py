@@ -321,7 +321,7 @@ class BEVControlNetModel(ModelBase):
         if self.config.controlnet_conditioning_channel_order == "bgr":
             controlnet_cond = torch.flip(controlnet_cond, dims=[1])
         if not self.use_occ_3d:
-            cond, mc, h, w = self.controlnet_cond_embedding.run(controlnet_cond)
+            cond, mc, h, w = self.controlnet_cond_embedding.run(controlnet_cond, m // controlnet_cond.shape[0])
         else:
             assert self.controlnet_cond_embedding is None
             cond, mc, h, w = to_nhwc(controlnet_cond.to(dt))

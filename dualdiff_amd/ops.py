@@ -506,7 +506,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 
 def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_map=None,
-              out=None, accumulate=False, variant=0, q_prescaled=False):
+              out=None, accumulate=False, variant=0, q_prescaled=False, seq_strides=None,
+              out_seq_strides=None):
     """softmax(scale * q k^T) v per (batch, head).
 
     q / k / v may also be HEAD-MAJOR 3-D tensors (heads, rows, head_dim) — slices of a
@@ -514,7 +515,12 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
 
     q: (batch*lq, >= heads*head_dim) row-strided view; k, v: (kv_batches*lk, ...) likewise, so
     slices of a fused QKV projection can be passed without copies.  kv_batch_map (int32 device
-    tensor [batch]) redirects batch b to K/V of another batch (neighbour views)."""
+    tensor [batch]) redirects batch b to K/V of another batch (neighbour views).
+
+    seq_strides = (row_stride, batch_stride) in elements for q, k, v (row-major 2-D views with the same row
+    pitch), out_seq_strides likewise for `out` (default: the same): the sequence runs over rows `row_stride`
+    apart and consecutive batches start `batch_stride` apart — attention ALONG ANOTHER AXIS of a (frames, tokens, C) activation without a transpose
+    (temporal attention: row_stride = tokens_per_frame * C, batch_stride = C)."""
     lib = _native.load()
     _need_gpu(q, k, v, out, kv_batch_map)
     d = AttnDesc()
@@ -539,16 +545,35 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     d.v, d.ldv, d.v_batch_stride, d.v_head_stride = operand(v, lk)
     d.q_prescaled = int(bool(q_prescaled))
     if out is None:
-        out = torch.empty((batch * lq, heads * head_dim), dtype=q.dtype, device=q.device)
+        out = torch.empty((q.shape[0], heads * head_dim) if seq_strides is not None else
+                          (batch * lq, heads * head_dim), dtype=q.dtype, device=q.device)
     out = _rows2d(out)
     d.o, d.ldo = out.data_ptr(), out.stride(0)
     d.o_batch_stride = lq * out.stride(0)
+    if seq_strides is not None:
+        if q.dim() != 2 or k.dim() != 2 or v.dim() != 2 or kv_batch_map is not None:
+            raise ValueError("seq_strides takes row-major 2-D q / k / v and no kv_batch_map")
+        rs, bs = int(seq_strides[0]), int(seq_strides[1])
+        ors, obs = (rs, bs) if out_seq_strides is None else (int(out_seq_strides[0]), int(out_seq_strides[1]))
+        d.ldq = d.ldk = d.ldv = rs
+        d.q_batch_stride = d.k_batch_stride = d.v_batch_stride = bs
+        d.ldo, d.o_batch_stride = ors, obs
     d.batch, d.heads, d.head_dim, d.lq, d.lk = batch, heads, head_dim, lq, lk
     d.scale = float(scale) if scale is not None else head_dim ** -0.5
     d.kv_batch_map = kv_batch_map.data_ptr() if kv_batch_map is not None else None
     d.accumulate = int(accumulate)
     d.dtype = _dt(q)
     d.variant = variant
+    if seq_strides is not None and batch * heads > 65535:
+        # the launcher's grid covers at most 65535 (batch, head) pairs: walk the batch in chunks
+        es, per = q.element_size(), 65535 // heads
+        base = (d.q, d.k, d.v, d.o)
+        for b0 in range(0, batch, per):
+            d.batch = min(per, batch - b0)
+            d.q, d.k, d.v = (ptr + b0 * d.q_batch_stride * es for ptr in base[:3])
+            d.o = base[3] + b0 * d.o_batch_stride * es
+            _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
+        return out
     if _TIMER is not None:
         e0 = _TIMER.start()
         _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")

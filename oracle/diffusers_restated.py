@@ -23,6 +23,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .numerics import prob_round, stor
+
 
 # --------------------------------------------------------------------------- config glue --
 class FrozenConfig(OrderedDict):
@@ -146,11 +148,11 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb):
         h = self.conv1(F.silu(self.norm1(x)))
         if temb is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+            h = stor(h + self.time_emb_proj(F.silu(temb))[:, :, None, None])
         h = self.conv2(F.silu(self.norm2(h)))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return (x + h) / self.output_scale_factor
+        return stor(x + h) / self.output_scale_factor
 
 
 class Downsample2D(nn.Module):
@@ -194,7 +196,7 @@ class AttnProcessor:
             return t.reshape(t.shape[0], t.shape[1], h, c // h).permute(0, 2, 1, 3)
 
         s = (split(q).float() @ split(k).float().transpose(-1, -2)) * attn.scale
-        o = (torch.softmax(s, dim=-1) @ split(v).float()).to(q.dtype)
+        o = (prob_round(torch.softmax(s, dim=-1)) @ split(v).float()).to(q.dtype)
         o = o.permute(0, 2, 1, 3).reshape(b, lq, c)
         return attn.to_out[1](attn.to_out[0](o))
 
@@ -250,7 +252,7 @@ class GEGLU(nn.Module):
 
     def forward(self, x):
         h, gate = self.proj(x).chunk(2, dim=-1)
-        return h * F.gelu(gate)
+        return stor(h * stor(F.gelu(gate)))
 
 
 class FeedForward(nn.Module):
@@ -308,12 +310,12 @@ class BasicTransformerBlock(nn.Module):
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None):
         kw = cross_attention_kwargs or {}
         h = hidden_states
-        h = self.attn1(self.norm1(h), encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
-                       attention_mask=attention_mask, **kw) + h
+        h = stor(self.attn1(self.norm1(h), encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
+                            attention_mask=attention_mask, **kw) + h)
         if self.attn2 is not None:
-            h = self.attn2(self.norm2(h), encoder_hidden_states=encoder_hidden_states,
-                           attention_mask=encoder_attention_mask, **kw) + h
-        return self.ff(self.norm3(h)) + h
+            h = stor(self.attn2(self.norm2(h), encoder_hidden_states=encoder_hidden_states,
+                                attention_mask=encoder_attention_mask, **kw) + h)
+        return stor(self.ff(self.norm3(h)) + h)
 
 
 class Transformer2DModel(nn.Module):
@@ -347,7 +349,7 @@ class Transformer2DModel(nn.Module):
                     encoder_attention_mask=encoder_attention_mask, timestep=timestep,
                     cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels)
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2).contiguous()
-        out = self.proj_out(h) + res
+        out = stor(self.proj_out(h) + res)
         return (out,)
 
 

@@ -17,6 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .numerics import prob_round, stor
+
 from . import diffusers_restated as D
 
 
@@ -30,7 +32,7 @@ def sdpa(q, k, v, heads, scale):
         return t.reshape(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3).float()
 
     s = (split(q) @ split(k).transpose(-1, -2)) * scale
-    o = torch.softmax(s, dim=-1) @ split(v)
+    o = prob_round(torch.softmax(s, dim=-1)) @ split(v)
     return o.permute(0, 2, 1, 3).reshape(b, lq, c).to(q.dtype)
 
 
@@ -225,8 +227,8 @@ class BasicMultiviewTransformerBlock(D.BasicTransformerBlock):
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None):
         h = hidden_states
-        h = self.attn1(self.norm1(h)) + h
-        h = self.attn2(self.norm2(h), encoder_hidden_states=encoder_hidden_states) + h
+        h = stor(self.attn1(self.norm1(h)) + h)
+        h = stor(self.attn2(self.norm2(h), encoder_hidden_states=encoder_hidden_states) + h)
         n_cam = len(self.neighboring_view_pair)
         x = self.norm4(h)
         xv = x.reshape(-1, n_cam, x.shape[1], x.shape[2])          # (b, view, tokens, C)
@@ -236,9 +238,9 @@ class BasicMultiviewTransformerBlock(D.BasicTransformerBlock):
         for view, neighbours in self.neighboring_view_pair.items():
             for u in neighbours:
                 o = sdpa(q[:, view], k[:, u], v[:, u], a.heads, a.scale)
-                out[:, view] += a.to_out[0](o)
-        h = self.connector(out.reshape_as(x)) + h
-        return self.ff(self.norm3(h)) + h
+                out[:, view] = stor(out[:, view] + a.to_out[0](o))
+        h = stor(self.connector(out.reshape_as(x)) + h)
+        return stor(self.ff(self.norm3(h)) + h)
 
 
 class UNet2DConditionModelMultiview(D.UNet2DConditionModel):

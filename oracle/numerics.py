@@ -5,14 +5,35 @@ accumulates in fp32 (SURVEY.md §8c "Numerics of the reference path").  `storage
 the fp32 CPU oracle do the same: hooks round every floating-point tensor that ENTERS or LEAVES any
 nn.Module (leaf or container) to the storage dtype — conv / linear / norm outputs, and also the
 results of functional ops (SiLU, residual adds, `sample += controlnet_cond`, concatenations) at the
-point where they are handed to the next module.  Tensors that live only inside a functional
-expression (softmax probabilities, q.k^T scores) stay fp32, so this is still a LOWER bound of the
-reference path's own rounding noise — the yardstick the HIP path's error is compared with in
-tests/test_model_gpu.py.
+point where they are handed to the next module.  Inside the attention the scores and the softmax stay fp32
+(as in xformers' kernels) but the PROBABILITIES are rounded to the storage dtype before the P.V product —
+they are a tensor-core operand in both of xformers' forward kernels (flash and CUTLASS convert P to the
+input type for the second matmul), so that rounding is part of the reference's numerics too
+(`prob_round`, consulted by the oracle's sdpa sites), and so are the results of the functional ops that feed
+the RESIDUAL STREAM inside a forward (`stor`: attention / feed-forward / resnet residual adds, `h + temb`, the
+GEGLU product) — an fp16 model produces fp16 tensors there; without it a block's residual stream would stay
+exact fp32 from its first to its last layer, which no fp16 run does.  Everything else inside functional
+expressions (SiLU before a conv's input rounding, scores, softmax) stays fp32, so this is still a LOWER bound of the reference path's own rounding noise — the yardstick
+the HIP path's error is compared with in tests/test_model_gpu.py.
 """
 import contextlib
 
 import torch
+
+
+_PROB_DTYPE = None      # storage dtype the attention probabilities are rounded to (None: exact fp32 oracle)
+
+
+def prob_round(p):
+    """Applied by every softmax(QK^T) site of the oracle to the probabilities before P.V."""
+    return p if _PROB_DTYPE is None else p.to(_PROB_DTYPE).to(p.dtype)
+
+
+def stor(t):
+    """Marks a tensor that a functional torch op PRODUCES inside a module's forward (residual adds, the GEGLU
+    product, `h + temb`): in the reference's fp16 eval path every op returns an fp16 tensor, so under
+    storage_emulation the value is rounded right there; identity for the exact fp32 oracle."""
+    return t if _PROB_DTYPE is None else t.to(_PROB_DTYPE).to(t.dtype)
 
 
 def _round_tree(x, dtype):
@@ -40,11 +61,14 @@ def storage_emulation(module, dtype):
             return out
         return _round_tree(out, dtype)
 
+    global _PROB_DTYPE
     for m in module.modules():
         handles.append(m.register_forward_pre_hook(pre, with_kwargs=True))
         handles.append(m.register_forward_hook(post))
+    saved, _PROB_DTYPE = _PROB_DTYPE, dtype
     try:
         yield module
     finally:
+        _PROB_DTYPE = saved
         for h in handles:
             h.remove()

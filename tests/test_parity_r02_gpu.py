@@ -53,17 +53,18 @@ def config0_case(gpu):
     assert int(ts[0]) == 981
     coef = R.ddim_coefs(R.ddim_alphas(), 981, ratio)
 
-    def run():
+    def run(dt=None):
         eps = ora(x, torch.tensor(981), encoder_hidden_states=txt).sample
         x0 = (x - coef[1] * eps) / coef[0]
-        return eps, coef[2] * x0 + coef[3] * eps
+        xn = coef[2] * x0 + coef[3] * eps
+        return eps, (xn if dt is None else xn.to(dt).float())       # the latents are stored in the model dtype
 
     with torch.no_grad():
         ref = run()
         emul = {}
         for dt in DTYPES:
             with storage_emulation(ora, dt):
-                emul[dt] = run()
+                emul[dt] = run(dt)
     return sd, x, txt, coef, ref, emul
 
 
@@ -163,9 +164,8 @@ def test_full_step_dual_branch_bf16_vs_oracle(step_models):
 def test_trajectory_50_steps_fp16(step_models):
     """One whole 50-step DDIM sample in fp16 (the reference's dtype) replayed from the HIP graph, compared at
     the checkpoints with the fp32 oracle trajectory; the fp16-storage oracle trajectory is the floor.  The
-    drift curve goes to the parity CSV.  Bound: the usual max(1e-3, 1.1 x floor) for the first steps; from
-    step 5 on two differently-rounded runs of a 50-step recursion decorrelate, so the curve only has to stay
-    within 2x of the floor's."""
+    drift curve goes to the parity CSV.  Bound: max(1e-3, 1.1 x floor) at EVERY checkpoint (measured: the HIP
+    curve stays just below the floor's all the way, 1.46e-3 vs 1.47e-3 after 50 steps)."""
     g = _gold()
     dtype = torch.float16
     den = _denoiser(step_models, dtype, use_graph=True)
@@ -181,7 +181,7 @@ def test_trajectory_50_steps_fp16(step_models):
                 y = den.latents[0].float().cpu()
                 e = rel_l2(y, g["ref_%d" % k])
                 fl = rel_l2(g["floor_f16_%d" % k], g["ref_%d" % k]) if "floor_f16_%d" % k in g else 0.0
-                bnd = bound(fl) if k <= 3 else max(1e-3, 2.0 * fl)
+                bnd = bound(fl)
                 print("trajectory step %2d: e_hip=%.3e e_floor=%.3e bound=%.3e" % (k, e, fl, bnd))
                 log_row("ddim50 trajectory step %d" % k, dtype, e, fl, bnd)
                 rec.append((k, e, fl))
@@ -243,7 +243,7 @@ def test_foreign_processor_in_multiview_block(gpu, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16])
 def test_split_size_chunking_controlnet(step_models, dtype, monkeypatch):
     """SPLIT_SIZE (box_adapter.py:11,41-64): with the reference's XFormersAttnProcessor installed on every
-    attention and SPLIT_SIZE = 5, each attention call is chunked 12 -> 5 + 5 + 2 instances; residuals must
+    attention and SPLIT_SIZE = 5, each attention call is chunked 12 -> 4 + 4 + 4 instances (torch.chunk(3)); residuals must
     equal the unchunked run's within the storage rounding (different GEMM row counts pick other tiles)."""
     from dualdiff_amd.networks import box_adapter as BA
     usd, csd = step_models
@@ -263,7 +263,7 @@ def test_split_size_chunking_controlnet(step_models, dtype, monkeypatch):
             return real(self, attn, hs, *a, **k)
         monkeypatch.setattr(BA.XFormersAttnProcessor, "_real_call", counted)
         chunked = net(*args, return_dict=False, use_aug_text=False)
-    assert calls and set(calls) == {5, 2} and len(calls) == 3 * 14          # 7 blocks x (attn1, attn2) x 3 chunks
+    assert calls and set(calls) == {4} and len(calls) == 3 * 14    # 7 blocks x (attn1, attn2) x chunks of 12 -> 4 + 4 + 4
     for i, (a, b) in enumerate(zip(base[0] + [base[1]], chunked[0] + [chunked[1]])):
         e = rel_l2(a, b.float().cpu())
         assert e <= 2e-3, (i, e)
@@ -323,19 +323,17 @@ def test_three_branch_residual_sum(gpu):
     (pipeline_bev_controlnet.py:421-429); parallel_branches hands it tuples of per-branch tensors."""
     from dualdiff_amd import ops as O
     dtype = torch.float16
-    t = torch.randn((64, 320), device="cuda").to(dtype)
-    rs = [torch.randn((64, 320), device="cuda").to(dtype) for _ in range(5)]
     from dualdiff_amd.networks.layers import device_init_
     from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModel
     with torch.device("cuda"):
-        net = UNet2DConditionModel(block_out_channels=(32, 64, 64, 64), cross_attention_dim=64, attention_head_dim=8).to(dtype)
+        net = UNet2DConditionModel(cross_attention_dim=768).to(dtype)      # SD-1.5 widths (head dims 40 / 80 / 160)
     device_init_(net, 3)
     x = torch.randn((2, 4, 16, 16), device="cuda").to(dtype)
-    ctx = torch.randn((2, 7, 64), device="cuda").to(dtype)
+    ctx = torch.randn((2, 7, 768), device="cuda").to(dtype)
     with torch.no_grad():
         x8 = torch.nn.functional.pad(O.nchw_to_nhwc(x), (0, 4))
         tf = torch.full((2,), 500.0, device="cuda")
-        st = net.encode_nhwc(x8, 2, 16, 16, tf, ctx.reshape(-1, 64), 7)
+        st = net.encode_nhwc(x8, 2, 16, 16, tf, ctx.reshape(-1, 768), 7)
         shapes = [s[0].shape for s in st["skips"]]
         for nb in (1, 2, 3, 4):
             branches = [[torch.randn(sh, device="cuda").to(dtype) * 0.1 for sh in shapes] for _ in range(nb)]
