@@ -33,7 +33,7 @@ class GemmDesc(Structure):
         ("ws", c_void_p), ("ws_bytes", c_int64),
         ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32), ("ln_stats_out", c_void_p), ("ln_stats_in", c_void_p),
         ("out_headmajor_d", c_int32), ("hm_scaled_planes", c_int32), ("hm_scale", c_float),
-        ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("w_scale", c_void_p),
     ]
 
 

@@ -45,6 +45,7 @@ struct GemmParams {
   const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
   int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
   const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
+  const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
 };
 
 template <typename T>
@@ -1151,7 +1152,19 @@ __device__ __forceinline__ void rp_load_vec(const T* src, float (&f)[VW]) {
   for (int e = 0; e < VW; ++e) f[e] = (float)tmp[e];
 }
 
-template <typename T, int KS, int TN, int TM, int NBUF, bool LN>
+// fp8 (OCP e4m3fn) -> T for 8 consecutive weights: one-time conversion when the fragments are loaded
+template <typename T>
+__device__ __forceinline__ typename dd_vec<T>::v8 rp_dequant8(u32x2 raw) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typename dd_vec<T>::v8 r;
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[0], true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[1], true);
+  r[0] = (T)a[0]; r[1] = (T)a[1]; r[2] = (T)b[0]; r[3] = (T)b[1];
+  r[4] = (T)c[0]; r[5] = (T)c[1]; r[6] = (T)d[0]; r[7] = (T)d[1];
+  return r;
+}
+
+template <typename T, int KS, int TN, int TM, int NBUF, bool LN, bool W8 = false>
 __global__ __launch_bounds__(256)
 void dd_gemm_rp_kernel(const GemmParams p) {
   using V8 = typename dd_vec<T>::v8;
@@ -1200,10 +1213,17 @@ void dd_gemm_rp_kernel(const GemmParams p) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int n = col0 + loc0 + tn * 4;
+      if constexpr (W8) {        // fp8 weights [n][K] bytes: 8 B per lane and k-step, dequantised to T once, here
+        const uint32_t vo = n < p.n ? (uint32_t)n * (uint32_t)K + (uint32_t)fq * 8u : DD_OOB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          wreg[tn][ks] = rp_dequant8<T>(__builtin_amdgcn_raw_buffer_load_b64(rs_w, vo + ks * 32, 0, 0));
+      } else {
       const uint32_t vo = n < p.n ? (uint32_t)n * (uint32_t)(K * 2) + (uint32_t)fq * 16u : DD_OOB;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         wreg[tn][ks] = dd_as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(rs_w, vo + ks * 64, 0, 0));
+      }
     }
   }
 
@@ -1249,7 +1269,13 @@ void dd_gemm_rp_kernel(const GemmParams p) {
   }
   // epilogue constants
   const int ecol0 = col0 + fq * (4 * TN);
-  float ebias[NG][VW];
+  float ebias[NG][VW], escale[NG][VW];
+  if constexpr (W8) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) escale[g][e] = p.w_scale[ecol0 + g * VW + e];
+  }
   if (p.bias) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.bias) + ecol0 + g * VW, ebias[g]);
@@ -1365,6 +1391,10 @@ void dd_gemm_rp_kernel(const GemmParams p) {
           for (int e = 0; e < VW; ++e) {
             const int c = g * VW + e;                    // channel inside the lane's 4*TN run
             v[e] = acc[c >> 2][j][c & 3];
+          }
+          if constexpr (W8) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] *= escale[g][e];
           }
           if (p.bias) {
 #pragma unroll
@@ -1508,7 +1538,7 @@ Plan make_plan(const dd_gemm_desc* d) {
     }
     if (kTiles[ti].stages <= 0 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }
-  if (d->ln_gamma && (ti < 0 || kTiles[ti].stages != -2)) {   // the LayerNorm prologue lives in the row-panel family
+  if ((d->ln_gamma || d->w_scale) && (ti < 0 || kTiles[ti].stages != -2)) {   // LayerNorm prologue / fp8 weights: row-panel family only
     if (d->tile > 0) { pl.unsupported = true; return pl; }
     for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 41) ti = i;
   }
@@ -1632,6 +1662,20 @@ int launch_rp(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr size_t smem = ((size_t)NBUF * TM * 16 * KS * 32 + 4 * 512 + 2 * KS * 32) * sizeof(T);
   static_assert(smem <= 160 * 1024, "LDS");
   dim3 grid(pl.tiles_m * pl.tiles_n);
+  if (p.w_scale) {             // fp8 weights (with or without the LayerNorm prologue)
+    if (p.ln_gamma) {
+      auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, true, true>;
+      static std::atomic<uint64_t> attr_done{0};
+      dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+      hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    } else {
+      auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, false, true>;
+      static std::atomic<uint64_t> attr_done{0};
+      dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+      hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    }
+    return dd_check_launch();
+  }
   if (p.ln_gamma) {
     auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, true>;
     static std::atomic<uint64_t> attr_done{0};
@@ -1731,6 +1775,11 @@ int validate(const dd_gemm_desc* d) {
     if (!dd_aligned16(d->ln_gamma) || !dd_aligned16(d->ln_beta) || (d->lda & 7)) return DD_ERR_BAD_ARG;
     if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
   }
+  if (d->w_scale) {                                    // fp8 weights (row-panel family)
+    if (d->conv || d->a2 || d->ln_colsum || d->epilogue != DD_EPI_NONE) return DD_ERR_UNSUPPORTED;
+    if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
+    if (!dd_aligned16(d->w_scale)) return DD_ERR_BAD_ARG;
+  }
   if (d->rows <= 0 || d->n <= 0 || d->k <= 0) return DD_ERR_BAD_ARG;
   if ((d->k & 7) || (d->n & 7) || (d->ldc & 7)) return DD_ERR_BAD_ARG;
   if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;
@@ -1827,6 +1876,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.ln_bias = reinterpret_cast<const float*>(d->ln_bias);
   p.ln_eps = d->ln_eps;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta;
+  p.w_scale = reinterpret_cast<const float*>(d->w_scale);
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;
@@ -1848,7 +1898,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   {
     const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
-    p.w_bytes = (uint32_t)(nw * d->k * 2);
+    p.w_bytes = (uint32_t)(nw * d->k * (d->w_scale ? 1 : 2));
     if (d->conv) {
       p.a_bytes = (uint32_t)((int64_t)d->rows / (d->hout * d->wout) * d->hin * d->win * d->cin * 2);
       p.a2_bytes = 0;

@@ -143,6 +143,8 @@ void dd_gn_apply_kernel(const GnParams p) {
   const int p1 = min(p.hw, p0 + p.pix_per_split);
   // The first batch of pixel vectors does not depend on the statistics: issue its loads BEFORE the
   // partial sums are fetched and combined, so the two memory round trips overlap.
+  // this thread's group pivot (threads < groups): loaded first so that it is back long before the combine
+  const float my_pivot = (int)threadIdx.x < p.groups ? gn_pivot<T>(p, inst, threadIdx.x) : 0.f;
   const int cv_first = mp.cv;
   const int ch_first = min(cv_first, mp.cv_count - 1) << 3;
   u32x4 pre[GN_UNROLL];
@@ -175,7 +177,7 @@ void dd_gn_apply_kernel(const GnParams p) {
       const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
       const float dm = a * inv_n;                        // mean - pivot
       const float var = fmaxf(b * inv_n - dm * dm, 0.f);
-      s_mean[threadIdx.x] = gn_pivot<T>(p, inst, threadIdx.x) + dm;
+      s_mean[threadIdx.x] = my_pivot + dm;
       s_rstd[threadIdx.x] = rsqrtf(var + p.eps);
     }
   }
@@ -231,7 +233,7 @@ template <typename T, int THREADS, int NVMAX>
 __global__ __launch_bounds__(THREADS)
 void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int kred) {
   __shared__ float s_a0[THREADS], s_a1[THREADS], s_q0[THREADS], s_q1[THREADS];
-  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ float s_mean[64], s_rstd[64], s_piv[64];
   const int inst = blockIdx.y;
   const int t = threadIdx.x;
   const bool active = t < vpp * plc;
@@ -257,6 +259,7 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
   float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
   const float piv0 = gn_pivot<T>(p, inst, blockIdx.x * gpb + g0);
   const float piv1 = gn_pivot<T>(p, inst, blockIdx.x * gpb + g1);
+  if (t < gpb) s_piv[t] = gn_pivot<T>(p, inst, blockIdx.x * gpb + t);     // for the combine (no late global load)
 #pragma unroll
   for (int i = 0; i < NVMAX; ++i) {
     if (i < nv) {
@@ -294,7 +297,7 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
       sq = dd_wave_sum(sq);
       if (lane == 0) {
         const float dm = sum * inv_n;                    // mean - pivot
-        s_mean[g] = gn_pivot<T>(p, inst, blockIdx.x * gpb + g) + dm;
+        s_mean[g] = s_piv[g] + dm;
         s_rstd[g] = rsqrtf(fmaxf(sq * inv_n - dm * dm, 0.f) + p.eps);
       }
     }
@@ -329,7 +332,7 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
 }
 
 constexpr int GNF_NV_SMALL = 8;      // 256-thread blocks
-constexpr int GNF_NV_BIG = 4;        // 1024-thread blocks (<= 128 VGPRs)
+constexpr int GNF_NV_BIG = 8;        // 1024-thread blocks (<= 128 VGPRs): up to 8 vectors -> 28x50 slabs of 40 channels fit
 
 // picks channels-per-block (whole groups, a multiple of 8, >= 40 channels) and the block size so
 // that a block's slab fits the register budget; false -> use the two-launch path
@@ -342,8 +345,11 @@ bool gn_fused_plan(int hw, int c, int groups, int* cpb, int* vpp, int* plc, int*
     const int v = cb / 8;
     // 256-thread blocks while the slab needs <= 4 vectors per thread, else 1024 threads (short
     // per-thread chain), else 256 threads up to the register budget
+    // DD_GN_BIG_CAP (A/B): vectors per thread allowed in the 1024-thread form; 4 = the round-1 behaviour
+    // (28x50 images take the two-launch path), 8 = one launch for 28x50 too (96 blocks of 1024 threads)
+    static const int big_cap = getenv("DD_GN_BIG_CAP") ? atoi(getenv("DD_GN_BIG_CAP")) : GNF_NV_BIG;
     const int try_th[3] = {256, 1024, 256};
-    const int try_cap[3] = {4, GNF_NV_BIG, GNF_NV_SMALL};
+    const int try_cap[3] = {4, big_cap < GNF_NV_BIG ? big_cap : GNF_NV_BIG, GNF_NV_SMALL};
     for (int pass = 0; pass < 3; ++pass) {
       const int th = try_th[pass];
       if (v > th) continue;

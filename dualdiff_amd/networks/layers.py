@@ -78,8 +78,24 @@ class Linear(_Cached):
             self.__dict__["_pk_w"] = _pad_cols(self.weight.detach().reshape(self.out_features, -1))
         return self.__dict__["_pk_w"]
 
+    fp8 = False        # extension (BASELINE configs[4]): multiply by e4m3fn weights + per-channel scales
+
+    @property
+    def w8(self):
+        """(float8_e4m3fn [n, k], fp32 scale [n]) of this layer's weight, packed lazily like w2d."""
+        if "_pk_w8" not in self.__dict__:
+            self.__dict__["_pk_w8"] = O.quantize_fp8(self.w2d)
+        return self.__dict__["_pk_w8"]
+
+    def _fp8_ok(self, kw):
+        return (self.fp8 and O.rowpanel_ok(self.in_features, self.out_features) and kw.get("a2") is None
+                and kw.get("epilogue", O.DD_EPI_NONE) == O.DD_EPI_NONE and not kw.get("ln_stats"))
+
     def run(self, x2d, **kw):
         """x2d: (rows, K) — fused-epilogue GEMM (see ops.gemm kwargs)."""
+        if self._fp8_ok(kw):
+            w8, sc = self.w8
+            return O.gemm(x2d, w8, self.bias, w_scale=sc, **kw)
         w = self.w2d
         if w.shape[1] != self.in_features:   # K padded to a multiple of 8 (e.g. cam2token 189 -> 192)
             x2d = torch.nn.functional.pad(x2d, (0, w.shape[1] - x2d.shape[1]))
@@ -89,7 +105,12 @@ class Linear(_Cached):
         """LayerNorm(norm) + this Linear.  Row-panel GEMM with the LayerNorm as its prologue where the family
         covers the shape (ln_direct_ok), else the algebraic fold when enabled, else two launches."""
         if ln_direct_ok(norm, self.in_features, self.out_features, kw):
+            if self._fp8_ok(kw):
+                w8, sc = self.w8
+                return O.gemm(x2d, w8, self.bias, w_scale=sc, ln_direct=(norm.weight, norm.bias, norm.eps), **kw)
             return O.gemm(x2d, self.w2d, self.bias, ln_direct=(norm.weight, norm.bias, norm.eps), **kw)
+        if self._fp8_ok(kw) and isinstance(norm, LayerNorm):
+            return self.run(norm.run(x2d), **kw)
         if not ln_fold_ok(norm, self.in_features, self.out_features, x2d):
             return self.run(norm.run(x2d), **kw)
         w, ln = fold_layernorm(self.__dict__, "_pk_ln", norm, [self.weight], [self.bias])
@@ -202,8 +223,11 @@ def want_ln_stats():
 
 # LayerNorm as the PROLOGUE of the row-panel projection GEMM (dd_gemm_desc.ln_gamma): the panel of un-normalised
 # rows is normalised in LDS before the MFMAs, so norm1 / norm2 / norm4 need no launch of their own and their
-# output never visits HBM.  DD_LN_DIRECT=0 restores LayerNorm kernel + GEMM.
-LN_DIRECT = __import__("os").environ.get("DD_LN_DIRECT", "1") != "0"
+# output never visits HBM.  Correct and parity-tested, but MEASURED SLOWER on config 2 (73.9 vs 81.2 steps/s
+# fp16): a workgroup owns a 128..320-column slice, so the LayerNorm of a row panel is recomputed by every
+# column slice (x5 .. x30 at C = 640 / 1280), and with one wave per SIMD the LayerNorm (VALU), MFMA and
+# epilogue (memory) phases of a panel do not overlap.  Off by default; DD_LN_DIRECT=1 enables it.
+LN_DIRECT = __import__("os").environ.get("DD_LN_DIRECT", "0") == "1"
 
 
 def ln_direct_ok(norm, k, n, kw=None):
@@ -401,6 +425,14 @@ class Attention(_Cached):
                 m.bias.detach() if m.bias is not None else m.weight.new_zeros(m.out_features) for m in mods]).contiguous()
         return self.__dict__[key]
 
+    fp8 = False        # extension: fused Q|K|V projection with e4m3fn weights (enable_fp8_weights)
+
+    def _fused_fp8(self, names):
+        key = "_pk_w8_" + "".join(names)
+        if key not in self.__dict__:
+            self.__dict__[key] = O.quantize_fp8(self._fused(names))
+        return self.__dict__[key]
+
     def _hm(self, planes):
         """head_major argument of the projection GEMMs: [rows][D] planes per head, the Q planes carrying
         scale * log2(e) (attention(..., q_prescaled=True))."""
@@ -411,6 +443,13 @@ class Attention(_Cached):
         (3*heads, rows, dim_head).  With `norm`, x2d is the un-normalised input and the LayerNorm is
         folded into the GEMM."""
         hm = self._hm(self.heads) if head_major else None
+        names = ("to_q", "to_k", "to_v")
+        if self.fp8 and O.rowpanel_ok(x2d.shape[1], 3 * self.inner_dim):
+            w8, sc = self._fused_fp8(names)
+            if norm is not None and ln_direct_ok(norm, x2d.shape[1], 3 * self.inner_dim):
+                return O.gemm(x2d, w8, self._fused_bias(names), w_scale=sc, head_major=hm,
+                              ln_direct=(norm.weight, norm.bias, norm.eps))
+            return O.gemm(x2d if norm is None else norm.run(x2d), w8, self._fused_bias(names), w_scale=sc, head_major=hm)
         if norm is not None:
             if ln_direct_ok(norm, x2d.shape[1], 3 * self.inner_dim):
                 return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")), self._fused_bias(("to_q", "to_k", "to_v")),
@@ -463,6 +502,24 @@ class Attention(_Cached):
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                               attention_mask=attention_mask, **kw)
+
+
+def enable_fp8_weights(model, on=True):
+    """EXTENSION (BASELINE configs[4], no reference semantics): every attention projection of `model` whose shape
+    the row-panel GEMM family covers (fused Q|K|V, to_q, to_out — K = C of the level) multiplies by e4m3fn
+    weights with per-output-channel scales (half the weight stream; fragments are dequantised once per kernel
+    when they enter registers).  Quantisation happens lazily from the CURRENT weights, so fold LoRA deltas
+    first (dualdiff_amd.lora.fold_lora_).  Returns the number of layers switched."""
+    n = 0
+    for mod in model.modules():
+        if isinstance(mod, Attention):
+            mod.fp8 = bool(on)
+            mod._drop_cache()
+            for lin in (mod.to_q, mod.to_out[0]):
+                lin.fp8 = bool(on)
+                lin._drop_cache()
+            n += 1
+    return n
 
 
 def prefetch_cross_kv(model, ctx2d, side):

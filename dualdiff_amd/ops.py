@@ -207,7 +207,10 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
         return total / iters
 
     cands = []
+    excl = {int(t) for t in _os.environ.get("DD_TUNE_EXCLUDE", "").split(",") if t.strip()}   # A/B experiments
     for tile in _TILES:
+        if tile in excl:
+            continue
         for split in _SPLITS:
             if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):
                 continue
@@ -297,7 +300,7 @@ def _rows2d(t):
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
          out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
-         ln_stats=False, head_major=None, ln_direct=None):
+         ln_stats=False, head_major=None, ln_direct=None, w_scale=None):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
     head_major = (D, scaled_planes, scale): the result comes back as (n / D, rows, D) — one contiguous
     [rows][D] plane per head of a fused Q|K|V projection, the first `scaled_planes` planes multiplied by
@@ -305,6 +308,9 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     out_f32: the result is stored as fp32 (attention logits that feed a softmax).
     ln_stats: the epilogue also leaves per-row partial sums of the output (n % 32 == 0) as `out._ln_stats`;
     a later gemm(out, ..., ln=...) picks them up instead of recomputing the row statistics.
+
+    w_scale (fp32 [n]) with `w` a torch.float8_e4m3fn [n, k] matrix: fp8 WEIGHTS with per-output-channel scales
+    (extension, quantize_fp8()); row-panel shapes only (rowpanel_ok()).
 
     ln_direct = (gamma, beta, eps): LayerNorm PROLOGUE of the row-panel kernels — `a` is the un-normalised
     input, every row panel is normalised in LDS (dd_layernorm's arithmetic) before it is multiplied; K in
@@ -369,6 +375,15 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
             if tuple(stats_in.shape) != (rows, k // 32, 2) or stats_in.dtype != torch.float32:
                 raise ValueError("stale LayerNorm statistics attached to the input")
             d.ln_stats_in = stats_in.data_ptr()
+    if w_scale is not None:
+        _need_gpu(w_scale)
+        if w.dtype != torch.float8_e4m3fn or w_scale.dtype != torch.float32 or w_scale.numel() != n_w:
+            raise ValueError("fp8 weights: w must be float8_e4m3fn [n, k] and w_scale fp32 [n]")
+        if a2 is not None or ln is not None or epilogue != DD_EPI_NONE or not rowpanel_ok(k, n):
+            raise ValueError("fp8 weights cover the row-panel shapes only (K in {320, 640, 1280}, plain epilogue)")
+        d.w_scale = w_scale.data_ptr()
+    elif w.dtype != a.dtype:
+        raise TypeError("gemm: weight dtype %s != activation dtype %s" % (w.dtype, a.dtype))
     if ln_direct is not None:
         if ln is not None or a2 is not None:
             raise ValueError("gemm(ln_direct=...) takes a single source and excludes the algebraic fold")
@@ -388,7 +403,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
                                       + (("f32",) if out_f32 else ()) + (("so",) if ln_stats else ())
                                       + (("si",) if stats_in is not None else ())
                                       + (("hm", head_major[0]) if head_major is not None else ())
-                                      + (("lnd",) if ln_direct is not None else ())
+                                      + (("lnd",) if ln_direct is not None else ()) + (("w8",) if w_scale is not None else ())
                                       + (("res",) if res is not None else ()) + (("acc",) if accumulate else ()),
                                       (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
@@ -750,6 +765,15 @@ def fourier_embed(x, freqs, include_input=True):
     _native.check(lib.dd_fourier_embed(_ptr(x), _ptr(out), rows, dims, arr, nf, int(include_input), code, code,
                                        _stream()), "fourier_embed")
     return out
+
+
+def quantize_fp8(w):
+    """[n, k] weight matrix -> (float8_e4m3fn [n, k], fp32 scale [n]): symmetric per-output-channel quantisation,
+    scale = max|w_row| / 448 (the e4m3fn maximum), round-to-nearest — the layout `gemm(..., w_scale=...)` takes."""
+    wf = w.detach().float()
+    scale = (wf.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn).contiguous()
+    return q, scale
 
 
 def rowpanel_ok(k, n):

@@ -147,6 +147,12 @@ typedef struct dd_gemm_desc {
    * (networks/blocks.py:150-222) without a LayerNorm launch.  ln_gamma / ln_beta: T [k]; eps in ln_eps. */
   const void* ln_gamma;    /* NULL = no prologue */
   const void* ln_beta;
+  /* fp8 WEIGHTS (EXTENSION, BASELINE configs[4]; dense mode, K in {320, 640, 1280}, row-panel tiles only): `w` is
+   * [n][k] OCP e4m3fn bytes (half the weight stream), w_scale fp32 [n] the per-output-channel dequantisation
+   * scale: out[r, c] = w_scale[c] * sum_k A[r, k] * fp8(W[c, k]) (+ bias ...).  The weight fragments are
+   * converted to the activation type once, when they are loaded into registers; MFMA and accumulation are as in
+   * the 16-bit path. */
+  const float* w_scale;    /* NULL = 16-bit weights */
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
