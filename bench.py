@@ -39,13 +39,25 @@ PEAK_HBM_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
 
 
-def build_models(dtype, device, dual=True):
-    from dualdiff_amd.networks.layers import device_init_
-    from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+def build_models(dtype, device, dual=True, frames=1, fp8=False, lora_rank=0):
+    from dualdiff_amd.networks.layers import device_init_, enable_fp8_weights
+    from dualdiff_amd.networks.unet_2d_condition_multiview import (UNet2DConditionModelMultiview,
+                                                                   UNet2DConditionModelMultiviewVideo)
     from dualdiff_amd.networks.unet_addon_rawbox import BEVControlNetModel
     with torch.device(device):
-        unet = UNet2DConditionModelMultiview(cross_attention_dim=768, neighboring_view_pair=PAIR).to(dtype)
+        if frames > 1:        # EXTENSION (configs[3]): ST-Attn + temporal attention in every transformer block
+            unet = UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR,
+                                                      n_frames=frames).to(dtype)
+        else:
+            unet = UNet2DConditionModelMultiview(cross_attention_dim=768, neighboring_view_pair=PAIR).to(dtype)
     device_init_(unet, 1)
+    if lora_rank:             # EXTENSION (configs[4]): a synthetic rank-r attention LoRA folded into the projections
+        from dualdiff_amd.lora import fold_lora_, lora_keys
+        g = torch.Generator(device=device).manual_seed(77)
+        lora = {k: torch.randn(shape, generator=g, device=device) * 0.02 for k, shape in sorted(lora_keys(unet, lora_rank).items())}
+        fold_lora_(unet, lora, 1.0)
+    if fp8:                   # EXTENSION (configs[4]): e4m3fn weights on the attention projections
+        enable_fp8_weights(unet)
     cns = []
     for i, occ3d in enumerate((False, True) if dual else (False,)):
         with torch.device(device):
@@ -60,6 +72,8 @@ def build_models(dtype, device, dual=True):
         cn.use_occ_3d = occ3d               # use_occ_3d: [false, true]
         if occ3d:
             cn.controlnet_cond_embedding = None
+        if fp8:
+            enable_fp8_weights(cn)
         cns.append(cn.eval())
     return unet.eval(), cns
 
@@ -261,7 +275,7 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
     from dualdiff_amd import ops as O
     from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
-    unet, cns = build_models(dtype, device)
+    unet, cns = build_models(dtype, device, frames=args.frames, fp8=args.fp8_weights, lora_rank=args.lora_rank)
     kw, pairs, shard_desc = {}, 1, None
     graph = not args.no_graph
     if args.parallelism == "cfg-split":
@@ -291,14 +305,15 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
                       parallel_branches=not args.serial_branches, **kw)
     seed = 1234 + (rank // pairs if pairs <= 2 else 0)
     with torch.no_grad():
-        den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=seed))
+        # video (extension): the T frames of a scene are T more 6-view "scenes" of the batch, frame-major
+        den.set_inputs(*synthetic_inputs(args.scenes * args.frames, dtype, device, seed=seed))
         if graph:
             try:
                 den.capture()
             except Exception as e:      # keep measuring on the same HIP kernels, eagerly launched
                 print("[bench] HIP-graph capture failed (%s); falling back to eager launches" % e, file=sys.stderr)
                 den.use_graph = graph = False
-                den.set_inputs(*synthetic_inputs(args.scenes, dtype, device, seed=seed))
+                den.set_inputs(*synthetic_inputs(args.scenes * args.frames, dtype, device, seed=seed))
 
         def barrier():
             torch.cuda.synchronize()
@@ -366,6 +381,14 @@ def main():
                          "type is measured in the same run and reported under `other_dtype` (--single-dtype skips it)")
     ap.add_argument("--single-dtype", action="store_true")
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
+    ap.add_argument("--frames", type=int, default=1,
+                    help="EXTENSION (BASELINE configs[3], no reference semantics): frames per scene; > 1 runs the video "
+                         "UNet (ST-Attn + temporal attention, dualdiff_amd/networks/video_blocks.py) on 2 x 6 x T "
+                         "view-instances per scene; a step then advances all T frames")
+    ap.add_argument("--fp8-weights", action="store_true",
+                    help="EXTENSION (configs[4]): e4m3fn weights + per-channel scales on the attention projections")
+    ap.add_argument("--lora-rank", type=int, default=0,
+                    help="EXTENSION (configs[4]): fold a synthetic rank-r attention LoRA into the UNet before running")
     ap.add_argument("--hoist-invariant", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--serial-branches", action="store_true",
@@ -431,7 +454,7 @@ def main():
     pairs = res["pairs"]
     scenes_total = max(1, args.scenes * world // pairs)
     value = args.steps * scenes_total / res["elapsed"]
-    step_tflop = (12 * GF_UNET + 24 * GF_CNET) / 1e3
+    step_tflop = (12 * GF_UNET + 24 * GF_CNET) / 1e3 * args.frames     # image-model count per frame (video adds ST / temporal attention)
     par = {"scenes": "scene-sharded x%d (no data-path collective)" % world,
            "cfg-split": "CFG halves split over rank pairs x%d (all-gather of the noise prediction per step)" % (world // 2),
            "view-split": "one scene over %d ranks: CFG halves x view shards, p2p neighbour-view K/V exchange per "
@@ -442,10 +465,16 @@ def main():
         "ms_per_step": res["elapsed"] / args.steps * 1e3 / args.scenes, "higher_is_better": True,
         "scaling": "weak" if pairs == 1 else "strong",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 6-view 224x400 (28x50 latents) multiview UNet + 2 ControlNet "
-                               "branches (ORS panorama + ORS-3D, SFA on), CFG 2.0 -> 12 view-instances/scene, "
-                               "DDIM-50 schedule, random-init weights",
+        "config": {"workload": ("BASELINE configs[1]: " if args.frames == 1 and not args.fp8_weights and not args.lora_rank
+                                else "EXTENSION of BASELINE configs[%d] (no reference semantics; see `extensions`) on the "
+                                     "configs[1] workload: " % (3 if args.frames > 1 else 4)) +
+                               "6-view 224x400 (28x50 latents) multiview UNet + 2 ControlNet "
+                               "branches (ORS panorama + ORS-3D, SFA on), CFG 2.0 -> 12 view-instances/scene"
+                               + (" x %d frames" % args.frames if args.frames > 1 else "") +
+                               ", DDIM-50 schedule, random-init weights",
                    "scenes_per_gpu": args.scenes, "parallelism": par,
+                   "extensions": {"frames_per_scene": args.frames, "fp8_attention_weights": args.fp8_weights,
+                                  "lora_rank_folded": args.lora_rank},
                    "hip_graph": res["graph"], "streams": 1 if args.serial_branches else 3,
                    "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
                    "algorithmic_tflop_per_step": step_tflop},

@@ -51,8 +51,13 @@ class VideoMultiviewTransformerBlock(BasicMultiviewTransformerBlock):
         # K/V of [first frame ; previous frame] per instance: (nb, T, V, 2 hd, 2, l, d)
         kv2 = torch.empty((nb, t_n, v_n, 2 * hd, 2, l, d), dtype=h.dtype, device=h.device)
         kv2[:, :, :, :, 0] = kv[:, :, :1].permute(1, 2, 3, 0, 4, 5)                 # broadcast over the frames
-        prev = [max(t - 1, 0) for t in range(t_n)]
-        kv2[:, :, :, :, 1] = kv[:, :, prev].permute(1, 2, 3, 0, 4, 5)
+        # previous-frame index, cached on the device (an index built from a Python list would be a host copy on
+        # the legacy stream — illegal inside HIP-graph capture)
+        key = (t_n, str(h.device))
+        if self.__dict__.get("_prev_idx", (None,))[0] != key:
+            self.__dict__["_prev_idx"] = (key, torch.tensor([max(t - 1, 0) for t in range(t_n)], device=h.device))
+        prev = self.__dict__["_prev_idx"][1]
+        kv2[:, :, :, :, 1] = kv.index_select(2, prev).permute(1, 2, 3, 0, 4, 5)
         flat = kv2.reshape(batch, 2 * hd, 2 * l, d)
         o = O.attention(qkv[:hd], flat[:, :hd], flat[:, hd:], batch, l, 2 * l, hd, d, q_prescaled=True)
         return a.to_out[0].run(o, res=h)
