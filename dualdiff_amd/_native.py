@@ -34,6 +34,7 @@ class GemmDesc(Structure):
         ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32), ("ln_stats_out", c_void_p), ("ln_stats_in", c_void_p),
         ("out_headmajor_d", c_int32), ("hm_scaled_planes", c_int32), ("hm_scale", c_float),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("w_scale", c_void_p),
+        ("phase", c_int32),
     ]
 
 
@@ -66,6 +67,7 @@ SIGNATURES = {
                                     c_int32, c_int32, c_int32, c_float, c_int32, c_int32,
                                     c_void_p, c_int64, c_void_p]),
     "dd_groupnorm_workspace_bytes": (c_int64, [c_int32, c_int32]),
+    "dd_groupnorm_is_fused": (c_int32, [c_int32, c_int32, c_int32]),
     "dd_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                c_int32, c_void_p]),
     "dd_attention": (c_int32, [POINTER(AttnDesc), c_void_p]),

@@ -1742,8 +1742,10 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
 
 template <typename T>
 int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t s) {
-  int rc;
-  if (d->epilogue == DD_EPI_GEGLU) {
+  int rc = DD_OK;
+  if (d->phase == 2) {                      // reduce launch only (per-launch timing of a split-K GEMM)
+    if (pl.split <= 1 || p.tile_counters) return DD_OK;
+  } else if (d->epilogue == DD_EPI_GEGLU) {
     if (d->conv) return DD_ERR_UNSUPPORTED;
     rc = launch_tile<T, false, true>(p, pl, s);
   } else if (d->conv) {
@@ -1752,7 +1754,7 @@ int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hip
     rc = launch_tile<T, false, false>(p, pl, s);
   }
   if (rc != DD_OK) return rc;
-  if (pl.split > 1 && !p.tile_counters) {
+  if (pl.split > 1 && !p.tile_counters && d->phase != 1) {
     const int64_t total = (int64_t)p.rows * (p.n / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

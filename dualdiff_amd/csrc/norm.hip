@@ -345,9 +345,10 @@ bool gn_fused_plan(int hw, int c, int groups, int* cpb, int* vpp, int* plc, int*
     const int v = cb / 8;
     // 256-thread blocks while the slab needs <= 4 vectors per thread, else 1024 threads (short
     // per-thread chain), else 256 threads up to the register budget
-    // DD_GN_BIG_CAP (A/B): vectors per thread allowed in the 1024-thread form; 4 = the round-1 behaviour
-    // (28x50 images take the two-launch path), 8 = one launch for 28x50 too (96 blocks of 1024 threads)
-    static const int big_cap = getenv("DD_GN_BIG_CAP") ? atoi(getenv("DD_GN_BIG_CAP")) : GNF_NV_BIG;
+    // DD_GN_BIG_CAP: vectors per thread allowed in the 1024-thread form.  4 (default): 28x50 images take the
+    // two-launch path; 8: one launch for 28x50 too — measured SLOWER (96 blocks of 1024 threads stream 112 KB
+    // each: 19.6 us per GroupNorm against 7.0 + 9.3 us for stats + apply over all CUs), kept for experiments.
+    static const int big_cap = getenv("DD_GN_BIG_CAP") ? atoi(getenv("DD_GN_BIG_CAP")) : 4;
     const int try_th[3] = {256, 1024, 256};
     const int try_cap[3] = {4, big_cap < GNF_NV_BIG ? big_cap : GNF_NV_BIG, GNF_NV_SMALL};
     for (int pass = 0; pass < 3; ++pass) {
@@ -543,6 +544,12 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
     hipLaunchKernelGGL(dd_gn_apply_kernel<__bf16>, grid, dim3(GN_THREADS), 0, s, p);
   }
   return dd_check_launch();
+}
+
+extern "C" int dd_groupnorm_is_fused(int32_t hw, int32_t c, int32_t groups) {
+  int cpb, vpp, plc, nv, kred, threads;
+  if (hw <= 0 || c <= 0 || groups <= 0 || c % groups) return 0;
+  return gn_fused_plan(hw, c, groups, &cpb, &vpp, &plc, &nv, &kred, &threads) ? threads : 0;
 }
 
 extern "C" int dd_layernorm(const void* x, const void* gamma, const void* beta, void* y,

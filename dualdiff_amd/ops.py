@@ -288,7 +288,29 @@ def workspace(nbytes, device, kind="gemm"):
 def _kname(lib, d):
     full = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
     name, rest = full.split(" split=")
-    return name if rest.startswith("1 ") else name + " +splitk_reduce"
+    return name, int(rest.split(" ")[0])
+
+
+def _timed_gemm(lib, d, what, suffix, flops, nbytes, rows, n):
+    """dd_gemm under the KernelTimer: a split-K GEMM's two launches are bracketed SEPARATELY (dd_gemm_desc.phase)
+    and booked under their own kernel symbols, so that every class of the roofline table is one kernel symbol
+    whose average duration can be checked against rocprofv3's."""
+    name, split = _kname(lib, d)
+    if split <= 1:
+        e0 = _TIMER.start()
+        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
+        _TIMER.stop(e0, name + suffix, flops, nbytes)
+        return
+    slab = 4.0 * split * rows * n
+    d.phase = 1
+    e0 = _TIMER.start()
+    _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
+    _TIMER.stop(e0, name + suffix, flops, nbytes + slab)             # operands once + the fp32 slabs written
+    d.phase = 2
+    e0 = _TIMER.start()
+    _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
+    _TIMER.stop(e0, "dd_splitk_reduce_kernel", 0.0, slab + 2.0 * rows * n)
+    d.phase = 0
 
 
 def _rows2d(t):
@@ -411,11 +433,9 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         ws = workspace(need, a.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
     if _TIMER is not None:
-        e0 = _TIMER.start()
-        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
-        _TIMER.stop(e0, _kname(lib, d) + (" gemm %dx%dx%d" % (rows, n_w, k) if _TIMER.shapes else ""),
-                    2.0 * rows * n_w * k,
-                    2.0 * (rows * k + n_w * k + rows * n * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))))
+        _timed_gemm(lib, d, "gemm", " gemm %dx%dx%d" % (rows, n_w, k) if _TIMER.shapes else "", 2.0 * rows * n_w * k,
+                    2.0 * (rows * k + n_w * k + rows * n * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))),
+                    rows, n)
     else:
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
     if stats_out is not None:
@@ -471,11 +491,10 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
         ws = workspace(need, x.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
     if _TIMER is not None:
-        e0 = _TIMER.start()
-        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
-        _TIMER.stop(e0, _kname(lib, d) + (" conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else ""),
+        _timed_gemm(lib, d, "conv3x3", " conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else "",
                     2.0 * rows * cout * 9 * cin,
-                    2.0 * (x.numel() + w.numel() + rows * cout * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))))
+                    2.0 * (x.numel() + w.numel() + rows * cout * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))),
+                    rows, cout)
         return out
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
     return out
@@ -499,7 +518,9 @@ def groupnorm(x, gamma, beta, m, hw, groups, eps, silu, x2=None, out=None):
                                _stream())
     _native.check(rc, "groupnorm")
     if e0 is not None:      # HBM-bound: each element read once and written once
-        _TIMER.stop(e0, "dd_groupnorm (gn_fused | gn_stats + gn_apply)", 0.0, 4.0 * out.numel())
+        th = lib.dd_groupnorm_is_fused(hw, c1 + c2, groups)
+        _TIMER.stop(e0, "dd_gn_fused_kernel<%d>" % th if th else "dd_gn_stats_kernel + dd_gn_apply_kernel (2 launches)",
+                    0.0, (4.0 if th else 6.0) * out.numel())
     return out
 
 

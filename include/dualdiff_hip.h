@@ -153,6 +153,10 @@ typedef struct dd_gemm_desc {
    * converted to the activation type once, when they are loaded into registers; MFMA and accumulation are as in
    * the 16-bit path. */
   const float* w_scale;    /* NULL = 16-bit weights */
+  /* A split-K GEMM is two launches (partial slabs, then reduce + epilogue).  phase = 0 enqueues both (normal use);
+   * 1 = the partial-slab launch only, 2 = the reduce launch only — so that a profiler-less caller (bench.py's
+   * HIP-event brackets) can time the two kernels separately.  Ignored when split-K is off. */
+  int32_t phase;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
@@ -179,6 +183,10 @@ int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int32_t c2,
                       int32_t apply_silu, int32_t dtype, void* ws, int64_t ws_bytes,
                       dd_stream_t stream);
 int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups);
+/* Which kernels dd_groupnorm_nhwc launches for an image of hw pixels x c channels: 256 / 1024 = ONE launch of
+ * dd_gn_fused_kernel with that many threads (slab in registers), 0 = dd_gn_stats_kernel + dd_gn_apply_kernel
+ * (for profile matching, like dd_gemm_kernel_name). */
+int dd_groupnorm_is_fused(int32_t hw, int32_t c, int32_t groups);
 
 /* LayerNorm over the last dim (eps 1e-5, affine) — BasicTransformerBlock
  * norm1/2/3 (diffusers) and norm4 (networks/blocks.py:67-71,191-194). */

@@ -8,7 +8,7 @@ from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
 
 if os.environ.get("DD_TUNE_CACHE") and os.path.exists(os.environ["DD_TUNE_CACHE"]):
     O.load_tuned(os.environ["DD_TUNE_CACHE"])
-dtype = torch.bfloat16
+dtype = torch.float16           # the headline dtype of bench.py
 dev = torch.device("cuda:0")
 unet, cns = bench.build_models(dtype, dev)
 den = BEVDenoiser(unet, cns, use_graph=False, parallel_branches=False)
