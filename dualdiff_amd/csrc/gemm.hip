@@ -916,12 +916,18 @@ void dd_conv3s_kernel(const GemmParams p) {
   const int lc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
   const uint32_t lcb = (uint32_t)lc * 16u;
 
+  // The activation slab is swizzled by ROW & 7 (the weight ring by (row >> 1) & 7 like the GEMM family): the tap
+  // gathers read 16 consecutive slab rows starting at ANY row (r + dy*W + dx), and ds_read_b128's lane groups
+  // ({0-3, 12-15} at chunk c, {4-11} at chunk c+1) are conflict-free for every such window only when the 8
+  // rows of a group get 8 different chunk positions whatever the window's parity — (row >> 1) & 7 does that
+  // for even shifts only (2-way conflicts on every odd tap: 34-39 % of the LDS cycles measured).
+  const uint32_t lcb_a = (uint32_t)((lane & 7) ^ (lane >> 3)) * 16u;
   // ---- DMA tables -----------------------------------------------------------------------
   uint32_t av[XA];                                      // activation rows of the tile (raw pixels)
 #pragma unroll
   for (int j = 0; j < XA; ++j) {
     const int r = (j * NW + wave) * 8 + lrow;
-    av[j] = r < vrows ? (uint32_t)(row0 + r) * (uint32_t)p.cin * 2u + lcb : DD_OOB;
+    av[j] = r < vrows ? (uint32_t)(row0 + r) * (uint32_t)p.cin * 2u + lcb_a : DD_OOB;
   }
   uint32_t wv[WI];                                      // weight rows, permuted like dd_gemm2_kernel
 #pragma unroll
@@ -950,14 +956,19 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int t = t2 * 2 + h;
-        uint32_t ra = BM;
+        // padding taps read one of the 16 zero rows BM .. BM+15, chosen so that the 16 lanes of an MFMA row
+        // block keep DISTINCT rows mod 16 — a valid tap reads row r + dy*W + dx, a padded one the zero row with
+        // the same residue — which is what keeps ds_read_b128 conflict-free under the (row >> 1) & 7 swizzle
+        // (one shared zero row cost 34-39 % of the LDS cycles in bank conflicts at the 4x7 / 7x13 levels,
+        // where a third of all taps are padding)
+        uint32_t ra = BM + ((uint32_t)(r + (t < 9 ? (t / 3 - 1) * p.wout + (t % 3 - 1) : 0)) & 15u);
         if (t < 9) {
           const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
           if (rv && iy >= 0 && iy < p.hout && ix >= 0 && ix < p.wout) ra = (uint32_t)(g * hw + iy * p.wout + ix);
         }
         // the entry is the fragment's LDS address in 16-byte units: row * 8 + swizzled chunk of k-step 0
         // (k-step 1 is the same address with bit 2 of the chunk flipped); AROWS * 8 + 7 < 2^16
-        ra = ra * 8u + ((uint32_t)(lane >> 4) ^ ((ra >> 1) & 7u));
+        ra = ra * 8u + ((uint32_t)(lane >> 4) ^ (ra & 7u));
         packed |= ra << (16 * h);
       }
       tab[tm][t2] = packed;
