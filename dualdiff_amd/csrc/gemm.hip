@@ -896,9 +896,11 @@ void dd_conv3s_kernel(const GemmParams p) {
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
 
+  // row tiles of ONE weight slice are neighbours in the remapped order -> same XCD, same L2: at these levels the
+  // weight matrix (29-59 MB) is the big operand and each slice is wanted by every row tile (activations: 1-3 MB)
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tile_m = tile / p.tiles_n;
-  const int tile_n = tile % p.tiles_n;
+  const int tile_n = p.upsample ? tile % p.tiles_n : tile / p.tiles_m;      // (upsample is unused by this kernel:
+  const int tile_m = p.upsample ? tile / p.tiles_n : tile % p.tiles_m;      //  A/B switch DD_CONV3S_ROWMAJOR=1)
   const int hw = p.hout * p.wout;
   const int m_inst = p.rows / hw;
   const int g0 = tile_m * p.g_per_tile;
@@ -1864,8 +1866,8 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
     return g_kname;
   }
   if (t.stages < 0) {
-    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
-             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4))), pl.split, pl.tiles_m, pl.tiles_n, t.name);
+    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4))), t.id >= 37 ? 3 : 1, pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
@@ -1904,6 +1906,10 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.hin = d->hin; p.win = d->win; p.cin = d->cin; p.hv = d->hv; p.wv = d->wv;
   p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;
   p.upsample = d->conv && (d->hv != d->hin || d->wv != d->win);
+  {
+    static const bool rowmajor = getenv("DD_CONV3S_ROWMAJOR") && atoi(getenv("DD_CONV3S_ROWMAJOR")) == 1;
+    if (kTiles[pl.tile_idx].stages == -1 && rowmajor) p.upsample = 1;         // conv3s never resizes: flag reused
+  }
   // torch nearest: src = min(floor(dst * (in/out)), in-1) with a float scale
   p.scale_h = d->conv ? (float)d->hin / (float)d->hv : 1.f;
   p.scale_w = d->conv ? (float)d->win / (float)d->wv : 1.f;
