@@ -250,7 +250,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
     // Rows are handled in (at most) two batches: per batch, phase 1 issues ALL its loads (clamped
     // addresses, nothing predicated), phase 2 does the arithmetic and the stores.  One batch would
     // keep TM*TN/2*3 16-B vectors live next to the accumulators (128x128 tile: > 256 VGPRs).
-    constexpr int TMB = TM >= 4 ? TM / 2 : TM;
+    constexpr int TMB = (TM >= 4 && TM % 2 == 0) ? TM / 2 : TM;      // batches must tile TM exactly
     u32x4 rb[NG];
     int colc[NG];
 #pragma unroll
@@ -1480,6 +1480,12 @@ constexpr TileCfg kTiles[] = {
     // tall tiles for the 4x7 / 7x13 levels (336 / 1092 rows x 1280 x up to 23040): all (or a third of)
     // the rows in one tile so the 29-59 MB weight matrix is streamed once, not once per 128 rows
     {26, 4, 2, 6, 2, 2, "384x64/dma2"},
+    // 160-wide tiles (10 waves = 2 x 5): every channel count of this network (320, 640, 960, 1280, 1920, 2560) is
+    // a multiple of 160, so no column of the tile multiplies padding (a 128-wide tile wastes 1/6 of its MFMAs at
+    // N = 320 and 16800 rows / 160 = 105 row tiles x 2 = 210 workgroups fill the chip in ONE generation)
+    {27, 2, 5, 5, 2, 2, "160x160/dma2"},
+    {28, 2, 5, 5, 2, 3, "160x160/dma3"},
+    {29, 2, 5, 5, 4, 2, "160x320/dma2"},            // GEGLU: 160 gated outputs per tile (h | g rows interleaved)
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -1744,6 +1750,9 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 24: return launch_cfg2<T, 2, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 25: return launch_cfg2<T, 2, 2, 4, 4, 4, CONV, GEGLU>(p, pl, s);
     case 26: if constexpr (!GEGLU) return launch_cfg2<T, 4, 2, 6, 2, 2, CONV, false>(p, pl, s); break;
+    case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
+    case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
+    case 29: return launch_cfg2<T, 2, 5, 5, 4, 2, CONV, GEGLU>(p, pl, s);
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
