@@ -46,6 +46,7 @@ struct GemmParams {
   int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
   const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
   const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
+  int no_stagger;                        // conv3s A/B switch (DD_CONV3S_STAGGER=0)
 };
 
 template <typename T>
@@ -809,7 +810,32 @@ void dd_gemm2_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // STAGGER (workgroups of >= 8 waves: two or more waves per SIMD behind ONE barrier per K-step would read LDS
+  // together and then contend for the matrix pipe together): the second half of the waves executes the MFMAs of
+  // K-step kt-1 (operands already in registers) BEFORE the fragment reads of K-step kt, i.e. half a step out of
+  // phase with the first half, so one wave's MFMAs run beside its SIMD partner's LDS traffic.  Same arithmetic
+  // in the same order per accumulator -> bit-identical results.  Fragments are double-buffered by step parity
+  // (compile-time: the loop is unrolled by two).  The direct conv kernel uses this (5.39 -> 4.78 us per 9 steps).
+  // MEASURED on this family (tiles 16 / 20 / 26, hot graph chains): 2-9 % SLOWER than the plain schedule (L0 conv
+  // 41.4 -> 45.0 us, GEGLU 53.0 -> 55.0 us, 16800x320x1600 27.3 -> 28.7 us) — unlike the direct conv, whose steps
+  // carry 12 tap gathers per wave; and the 10-wave 160-wide tiles (168 VGPRs) would spill.  Compiled out.
+  constexpr bool STAG = false;
+  const bool late = STAG && wave >= NW / 2 && !p.no_stagger;
+  V8 wf[STAG ? 2 : 1][2][TN], xf[STAG ? 2 : 1][2][TM];
+  auto mfma_step = [&](auto par_c) __attribute__((always_inline)) {
+    constexpr int par = decltype(par_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto kstep = [&](const int kt, auto par_c) __attribute__((always_inline)) {
+    constexpr int par = STAG ? decltype(par_c)::value : 0;
     // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
     if (NSTAGE == 2) {
       wait_vmcnt<0>();
@@ -826,30 +852,36 @@ void dd_gemm2_kernel(const GemmParams p) {
     __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
     // (issuing the DMAs after the fragment reads, or between the two MFMA halves, measured the same)
     if (kt + NSTAGE - 1 < nk) issue_next((kt + NSTAGE - 1) % NSTAGE);
+    if constexpr (STAG) {
+      if (late && kt > 0) mfma_step(std::integral_constant<int, par ^ 1>{});
+    }
     const int slot = kt % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
     const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
     // all fragment reads of the K-step go out first; the MFMAs of the first half then run while the
     // second half's reads are still landing (counted lgkmcnt waits, reads return in order)
-    V8 wf[2][TN], xf[2][TM];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+      for (int i = 0; i < TN; ++i) wf[par][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
+      for (int j = 0; j < TM; ++j) xf[par][ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+    if (!late) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(std::integral_constant<int, par>{});
     }
-    __builtin_amdgcn_s_setprio(0);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) kstep(kt + 1, std::integral_constant<int, 1>{});
+  }
+  if constexpr (STAG) {
+    if (late && nk > 0) {                  // the last K-step's MFMAs of the staggered waves
+      if ((nk - 1) & 1) mfma_step(std::integral_constant<int, 1>{});
+      else mfma_step(std::integral_constant<int, 0>{});
+    }
   }
   const bool ln = !CONV && p.ln_colsum;
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
@@ -909,6 +941,7 @@ void dd_conv3s_kernel(const GemmParams p) {
   const int row0 = g0 * hw;                             // first global output row
   const int block_n0 = tile_n * BN;
 
+  const bool stagger_off = p.no_stagger != 0;
   const int nchunks = p.cin / BK;
   const int c_beg = blockIdx.z * p.chunks_per_split;
   const int nc = min(nchunks, c_beg + p.chunks_per_split) - c_beg;
@@ -1014,6 +1047,8 @@ void dd_conv3s_kernel(const GemmParams p) {
   // are already being read.  The buffer index is a compile-time parity, so the chunk loop is
   // unrolled by two (9 taps per chunk is odd).
   V8 xf[2][2][TM];
+  V8 wf[2][2][TN];                                      // weight fragments, by step parity (see STAGGER below)
+  const bool late = NW == 8 && GRP == 1 && wave >= 4 && !stagger_off;
   auto gather = [&](const T* ab, auto tap_c, auto par_c) __attribute__((always_inline)) {
     constexpr int t = decltype(tap_c)::value;
     constexpr int par = decltype(par_c)::value;
@@ -1065,12 +1100,26 @@ void dd_conv3s_kernel(const GemmParams p) {
     }
     const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
     if (++wslot == NSW) wslot = 0;
-    V8 wf[2][TN];
+    // STAGGER (8-wave tiles): the two waves of a SIMD run the same program behind one barrier per step, so
+    // without help they read LDS together and then contend for the matrix pipe together.  Waves 4-7 execute
+    // the MFMAs of step s-1 (operands already in registers) BEFORE the reads of step s, i.e. half a step out
+    // of phase with waves 0-3: one wave's MFMAs run beside the other's LDS traffic.  Same arithmetic, same
+    // order per accumulator -> bit-identical results (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+    if (late && s > 0) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par ^ 1][ks][i], xf[par ^ 1][ks][j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+      for (int i = 0; i < TN; ++i) wf[par][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
     }
     if (s == 0) gather(abuf, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // first step only
     // next step's activation fragments (other parity)
@@ -1079,15 +1128,17 @@ void dd_conv3s_kernel(const GemmParams p) {
     } else if (more_c) {
       gather(abuf + ((c + 1) & 1) * AROWS * BK, std::integral_constant<int, 0>{}, std::integral_constant<int, par ^ 1>{});
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!late) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[par][ks][j], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
+          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
   };
   auto chunk = [&](const int c, auto par0) __attribute__((always_inline)) {
     constexpr int p0 = decltype(par0)::value;
@@ -1104,6 +1155,19 @@ void dd_conv3s_kernel(const GemmParams p) {
   for (int c = 0; c < nc; c += 2) {
     chunk(c, std::integral_constant<int, 0>{});            // even chunk: tap t uses parity t & 1
     if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{});   // odd chunk: parity (t + 1) & 1
+  }
+  if (late && nsteps > 0) {                               // staggered waves: the last step's MFMAs are still due
+    auto drain = [&](auto par_c) __attribute__((always_inline)) {
+      constexpr int par = decltype(par_c)::value;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+    };
+    if ((nsteps - 1) & 1) drain(std::integral_constant<int, 1>{});
+    else drain(std::integral_constant<int, 0>{});
   }
   // rows past the tile's instances are padding
   store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows),
@@ -1752,7 +1816,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 26: if constexpr (!GEGLU) return launch_cfg2<T, 4, 2, 6, 2, 2, CONV, false>(p, pl, s); break;
     case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
     case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
-    case 29: return launch_cfg2<T, 2, 5, 5, 4, 2, CONV, GEGLU>(p, pl, s);
+    case 29: if constexpr (GEGLU) return launch_cfg2<T, 2, 5, 5, 4, 2, false, true>(p, pl, s); break;   // 168 VGPRs: only the GEGLU form fits without spills
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
@@ -1916,6 +1980,8 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;
   p.upsample = d->conv && (d->hv != d->hin || d->wv != d->win);
   {
+    static const bool nostag = getenv("DD_STAGGER") && atoi(getenv("DD_STAGGER")) == 0;      // A/B switch
+    p.no_stagger = nostag ? 1 : 0;
     static const bool rowmajor = getenv("DD_CONV3S_ROWMAJOR") && atoi(getenv("DD_CONV3S_ROWMAJOR")) == 1;
     if (kTiles[pl.tile_idx].stages == -1 && rowmajor) p.upsample = 1;         // conv3s never resizes: flag reused
   }
