@@ -46,8 +46,16 @@ struct GemmParams {
   int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
   const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
   const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
-  int no_stagger;                        // conv3s A/B switch (DD_CONV3S_STAGGER=0)
+  int no_stagger;                        // conv3s A/B switch (DD_STAGGER=0)
+  float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
 };
+
+// n / d for 0 <= n < 2^22 (host-checked: rows) and the host-side inv = 1.0f / d: (n + 0.5) * inv is never within
+// float rounding of an integer boundary there (error <= 2^-23 * (n + 0.5) / d < 0.5 / d), so truncation gives the exact quotient — 3 VALU
+// instructions instead of the ~35 of a 32-bit integer division (the table-building prologues divide by the
+// image size and width once per tile row: a third of the direct conv kernel's VALU instructions).
+__device__ __forceinline__ int dd_fdiv(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
 
 template <typename T>
 __device__ __forceinline__ void store8(const GemmParams& p, int64_t row, int col, float (&v)[8]) {
@@ -80,7 +88,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int row, in
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if (p.rowvec) {
-    const int inst = row / p.rows_per_inst;
+    const int inst = dd_fdiv(row, p.inv_rpi);
     float b[8];
     dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.rowvec) + (int64_t)inst * p.ld_rowvec + col), b);
 #pragma unroll
@@ -277,7 +285,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
       for (int t2 = 0; t2 < TMB; ++t2) {
         const int rowc = min(row0 + (tb + t2) * 16, p.rows - 1);
         if (p.rowvec) {
-          const int inst = rowc / p.rows_per_inst;
+          const int inst = dd_fdiv(rowc, p.inv_rpi);
 #pragma unroll
           for (int g8 = 0; g8 < NG; ++g8)
             rv[t2][g8] = dd_ld16(reinterpret_cast<const T*>(p.rowvec) + (int64_t)inst * p.ld_rowvec + colc[g8]);
@@ -413,9 +421,9 @@ void dd_gemm_kernel(const GemmParams p) {
     if (r < p.rows) {
       if (CONV) {
         const int hw = p.hout * p.wout;
-        const int inst = r / hw;
+        const int inst = dd_fdiv(r, p.inv_hw);
         const int rem = r - inst * hw;
-        const int oy = rem / p.wout;
+        const int oy = dd_fdiv(rem, p.inv_wout);
         const int ox = rem - oy * p.wout;
         xm[i] = inst;
         xiy[i] = oy * p.stride - 1;
@@ -661,9 +669,9 @@ void dd_gemm2_kernel(const GemmParams p) {
     if (CONV) {
       const int hw = p.hout * p.wout;
       const int rr = rv ? r : 0;
-      const int inst = rr / hw;
+      const int inst = dd_fdiv(rr, p.inv_hw);
       const int rem = rr - inst * hw;
-      const int oy = rem / p.wout;
+      const int oy = dd_fdiv(rem, p.inv_wout);
       const int ox = rem - oy * p.wout;
       const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
       uint32_t bits = 0;
@@ -934,7 +942,7 @@ void dd_conv3s_kernel(const GemmParams p) {
   const int tile_n = p.upsample ? tile % p.tiles_n : tile / p.tiles_m;      // (upsample is unused by this kernel:
   const int tile_m = p.upsample ? tile / p.tiles_n : tile % p.tiles_m;      //  A/B switch DD_CONV3S_ROWMAJOR=1)
   const int hw = p.hout * p.wout;
-  const int m_inst = p.rows / hw;
+  const int m_inst = dd_fdiv(p.rows, p.inv_hw);
   const int g0 = tile_m * p.g_per_tile;
   const int ng = min(p.g_per_tile, m_inst - g0);
   const int vrows = ng * hw;                            // valid rows of this tile
@@ -981,9 +989,9 @@ void dd_conv3s_kernel(const GemmParams p) {
     const int r = wave_m * (TM * 16) + tm * 16 + (lane & 15);
     const bool rv = r < vrows;
     const int rr = rv ? r : 0;
-    const int g = rr / hw;
+    const int g = dd_fdiv(rr, p.inv_hw);
     const int rem = rr - g * hw;
-    const int y = rem / p.wout;
+    const int y = dd_fdiv(rem, p.inv_wout);
     const int x = rem - y * p.wout;
 #pragma unroll
     for (int t2 = 0; t2 < 5; ++t2) {
@@ -1869,6 +1877,7 @@ int validate(const dd_gemm_desc* d) {
     if (!dd_aligned16(d->w_scale)) return DD_ERR_BAD_ARG;
   }
   if (d->rows <= 0 || d->n <= 0 || d->k <= 0) return DD_ERR_BAD_ARG;
+  if (d->rows >= (1 << 22)) return DD_ERR_UNSUPPORTED;         // dd_fdiv's exactness bound (largest real case: 1.08 M)
   if ((d->k & 7) || (d->n & 7) || (d->ldc & 7)) return DD_ERR_BAD_ARG;
   if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;
   if (!dd_aligned16(d->a) || !dd_aligned16(d->w) || !dd_aligned16(d->out)) return DD_ERR_BAD_ARG;
@@ -1990,6 +1999,9 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.scale_w = d->conv ? (float)d->win / (float)d->wv : 1.f;
   p.k_per_split = pl.k_per_split;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.inv_hw = d->conv ? 1.0f / (float)(d->hout * d->wout) : 1.0f;
+  p.inv_wout = d->conv ? 1.0f / (float)d->wout : 1.0f;
+  p.inv_rpi = 1.0f / (float)p.rows_per_inst;
   {
     const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
     p.w_bytes = (uint32_t)(nw * d->k * (d->w_scale ? 1 : 2));
