@@ -35,6 +35,7 @@ class GemmDesc(Structure):
         ("out_headmajor_d", c_int32), ("hm_scaled_planes", c_int32), ("hm_scale", c_float),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("w_scale", c_void_p),
         ("phase", c_int32),
+        ("ln_out", c_void_p), ("ld_ln_out", c_int64), ("lno_gamma", c_void_p), ("lno_beta", c_void_p),
     ]
 
 

@@ -48,6 +48,8 @@ struct GemmParams {
   const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
   int no_stagger;                        // conv3s A/B switch (DD_STAGGER=0)
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
+  void* ln_out; int64_t ld_ln_out;       // LayerNorm EMITTED by the epilogue of the 80x320 tile (second output)
+  const void* lno_gamma; const void* lno_beta;
 };
 
 // n / d for 0 <= n < 2^22 (host-checked: rows) and the host-side inv = 1.0f / d: (n + 0.5) * inv is never within
@@ -573,6 +575,92 @@ void dd_gemm_kernel(const GemmParams p) {
 //  * counted s_waitcnt vmcnt(N) + raw s_barrier: one barrier per K-step, loads stay in flight
 //    across it.
 // =============================================================================================
+// ---- epilogue of the 80 x 320 tile that ALSO emits LayerNorm(out) ---------------------------------------------
+// A workgroup of 10 waves (1 x 10, TM = 5, TN = 2) owns 80 WHOLE rows of a 320-wide output: after bias / alpha /
+// residual it rounds the row to T (what the next layer reads), stores it, and normalises it right there — two-pass
+// fp32 statistics over the rounded values (the arithmetic of dd_layernorm), partial sums of the 10 waves combined
+// through LDS in a fixed order (bit-reproducible) — writing LayerNorm(out) as a second tensor.  The producer of
+// the residual stream thereby hands the next sub-layer its normalised input: no LayerNorm launch, no re-read of
+// the stream (norm1 / norm2 / norm3 / norm4 of the 28x50 level, blocks.py:150-236).
+template <typename T>
+__device__ __forceinline__ void store_tile_ln(const GemmParams& p, f32x4 (&acc)[2][5], int block_m0, int wave_n,
+                                              int lane, float* scratch) {
+  constexpr int TM = 5, NWV = 10, BM = 80, NCOL = 320;
+  const int q = lane >> 4, c = lane & 15;
+  const int col = wave_n * 32 + q * 8;
+  float bias[8], ga[8], be[8];
+  if (p.bias) dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.bias) + col), bias);
+  dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.lno_gamma) + col), ga);
+  dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.lno_beta) + col), be);
+  u32x4 rr[TM];
+  if (p.res) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int64_t rowc = min(block_m0 + tm * 16 + c, p.rows - 1);
+      rr[tm] = dd_ld16(reinterpret_cast<const T*>(p.res) + rowc * p.ldres + col);
+    }
+  }
+  float v[TM][8], part[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = block_m0 + tm * 16 + c;
+    float r[8];
+    if (p.res) dd_unpack8<T>(rr[tm], r);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = acc[e >> 2][tm][e & 3];
+      if (p.bias) x += bias[e];
+      x *= p.alpha;
+      if (p.res) x += r[e];
+      v[tm][e] = (float)(T)x;                            // the stored (rounded) value is what gets normalised
+      s += v[tm][e];
+    }
+    if (row < p.rows) dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v[tm]));
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    part[tm] = s;
+  }
+  __syncthreads();                                       // every wave is done with the operand ring: LDS is scratch now
+  if (q == 0) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) scratch[wave_n * BM + tm * 16 + c] = part[tm];
+  }
+  __syncthreads();
+  float mean[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) s += scratch[w * BM + tm * 16 + c];
+    mean[tm] = s * (1.0f / (float)NCOL);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[tm][e] - mean[tm]; ss += d * d; }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    part[tm] = ss;
+  }
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) scratch[wave_n * BM + tm * 16 + c] = part[tm];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = block_m0 + tm * 16 + c;
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) ss += scratch[w * BM + tm * 16 + c];
+    const float rstd = rsqrtf(ss * (1.0f / (float)NCOL) + p.ln_eps);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[tm][e] - mean[tm]) * rstd * ga[e] + be[e];
+    if (row < p.rows) dd_st16(reinterpret_cast<T*>(p.ln_out) + (int64_t)row * p.ld_ln_out + col, dd_pack8<T>(o));
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -889,6 +977,12 @@ void dd_gemm2_kernel(const GemmParams p) {
     if (late && nk > 0) {                  // the last K-step's MFMAs of the staggered waves
       if ((nk - 1) & 1) mfma_step(std::integral_constant<int, 1>{});
       else mfma_step(std::integral_constant<int, 0>{});
+    }
+  }
+  if constexpr (!CONV && !GEGLU && WAVES_M == 1 && WAVES_N == 10 && TM == 5 && TN == 2) {
+    if (p.ln_out) {                       // whole rows in this workgroup: store out AND LayerNorm(out)
+      store_tile_ln<T>(p, acc, block_m0, wave_n, lane, reinterpret_cast<float*>(smem));
+      return;
     }
   }
   const bool ln = !CONV && p.ln_colsum;
@@ -1558,6 +1652,9 @@ constexpr TileCfg kTiles[] = {
     {27, 2, 5, 5, 2, 2, "160x160/dma2"},
     {28, 2, 5, 5, 2, 3, "160x160/dma3"},
     {29, 2, 5, 5, 4, 2, "160x320/dma2"},            // GEGLU: 160 gated outputs per tile (h | g rows interleaved)
+    // 80 WHOLE rows of a 320-wide output per workgroup (1 x 10 waves): the only tile whose epilogue can emit
+    // LayerNorm(out) as a second tensor (dd_gemm_desc.ln_out); 16800 rows -> 210 workgroups, one generation
+    {40, 1, 10, 5, 2, 2, "80x320/dma2"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -1628,6 +1725,11 @@ Plan make_plan(const dd_gemm_desc* d) {
       for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == twin[ti < 4 ? ti : 3]) { ti = i; break; }
     }
     if (kTiles[ti].stages <= 0 || !dma_ok(d)) { pl.unsupported = true; return pl; }
+  }
+  if (d->ln_out) {                                   // LayerNorm-emitting epilogue: the 80x320 tile, one column tile
+    if (d->tile > 0 && d->tile != 40) { pl.unsupported = true; return pl; }
+    for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 40) ti = i;
+    if (d->n != 320 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }
   if ((d->ln_gamma || d->w_scale) && (ti < 0 || kTiles[ti].stages != -2)) {   // LayerNorm prologue / fp8 weights: row-panel family only
     if (d->tile > 0) { pl.unsupported = true; return pl; }
@@ -1702,7 +1804,7 @@ Plan make_plan(const dd_gemm_desc* d) {
       if (split < 1) split = 1;
     }
   }
-  if (geglu || d->ln_colsum || d->ln_stats_out || d->out_headmajor_d) split = 1;
+  if (geglu || d->ln_colsum || d->ln_stats_out || d->out_headmajor_d || d->ln_out) split = 1;
   if (split > nkt) split = nkt;
   int kts = ceil_div(nkt, split);
   split = ceil_div(nkt, kts);
@@ -1824,6 +1926,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 26: if constexpr (!GEGLU) return launch_cfg2<T, 4, 2, 6, 2, 2, CONV, false>(p, pl, s); break;
     case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
     case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
+    case 40: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 1, 10, 5, 2, 2, false, false>(p, pl, s); break;
     case 29: if constexpr (GEGLU) return launch_cfg2<T, 2, 5, 5, 4, 2, false, true>(p, pl, s); break;   // 168 VGPRs: only the GEGLU form fits without spills
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
@@ -1870,6 +1973,14 @@ int validate(const dd_gemm_desc* d) {
     if (!d->ln_beta || d->conv || d->a2 || d->ln_colsum) return DD_ERR_BAD_ARG;
     if (!dd_aligned16(d->ln_gamma) || !dd_aligned16(d->ln_beta) || (d->lda & 7)) return DD_ERR_BAD_ARG;
     if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
+  }
+  if (d->ln_out) {                                     // LayerNorm emitted by the epilogue (80x320 tile)
+    if (!d->lno_gamma || !d->lno_beta || d->conv || d->epilogue != DD_EPI_NONE || d->rowvec || d->accumulate ||
+        d->out_f32 || d->out_headmajor_d || d->ln_stats_out || d->ln_colsum || d->ln_gamma || d->w_scale)
+      return DD_ERR_UNSUPPORTED;
+    if (d->n != 320) return DD_ERR_UNSUPPORTED;
+    if (!dd_aligned16(d->ln_out) || !dd_aligned16(d->lno_gamma) || !dd_aligned16(d->lno_beta) || (d->ld_ln_out & 7))
+      return DD_ERR_BAD_ARG;
   }
   if (d->w_scale) {                                    // fp8 weights (row-panel family)
     if (d->conv || d->a2 || d->ln_colsum || d->epilogue != DD_EPI_NONE) return DD_ERR_UNSUPPORTED;
@@ -1974,6 +2085,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.ln_eps = d->ln_eps;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta;
   p.w_scale = reinterpret_cast<const float*>(d->w_scale);
+  p.ln_out = d->ln_out; p.ld_ln_out = d->ld_ln_out; p.lno_gamma = d->lno_gamma; p.lno_beta = d->lno_beta;
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;

@@ -91,8 +91,15 @@ class Linear(_Cached):
         return (self.fp8 and O.rowpanel_ok(self.in_features, self.out_features) and kw.get("a2") is None
                 and kw.get("epilogue", O.DD_EPI_NONE) == O.DD_EPI_NONE and not kw.get("ln_stats"))
 
-    def run(self, x2d, **kw):
-        """x2d: (rows, K) — fused-epilogue GEMM (see ops.gemm kwargs)."""
+    def run(self, x2d, ln_next=None, **kw):
+        """x2d: (rows, K) — fused-epilogue GEMM (see ops.gemm kwargs).  ln_next: the LayerNorm module that will
+        read the result next; where the 80x320 tile applies (out_features == 320) the epilogue emits its output
+        too and `ln_next.run(result)` becomes a cache hit (no launch)."""
+        if ln_next is not None and ln_producer_ok(self, ln_next, kw):
+            w = self.w2d
+            out = O.gemm(x2d, w, self.bias, ln_out=(ln_next.weight, ln_next.bias, ln_next.eps), **kw)
+            out._ln_cache = (ln_next, out._ln_out)
+            return out
         if self._fp8_ok(kw):
             w8, sc = self.w8
             return O.gemm(x2d, w8, self.bias, w_scale=sc, **kw)
@@ -186,6 +193,9 @@ class LayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.empty(dim))
 
     def run(self, x2d):
+        hit = getattr(x2d, "_ln_cache", None)          # LayerNorm already emitted by the producer's epilogue
+        if hit is not None and hit[0] is self:
+            return hit[1]
         return O.layernorm(x2d, self.weight, self.bias, self.eps)
 
     def forward(self, x):
@@ -228,6 +238,22 @@ def want_ln_stats():
 # column slice (x5 .. x30 at C = 640 / 1280), and with one wave per SIMD the LayerNorm (VALU), MFMA and
 # epilogue (memory) phases of a panel do not overlap.  Off by default; DD_LN_DIRECT=1 enables it.
 LN_DIRECT = __import__("os").environ.get("DD_LN_DIRECT", "0") == "1"
+
+
+# LayerNorm emitted by the PRODUCER's epilogue (dd_gemm_desc.ln_out): the GEMM that writes the residual stream at
+# the 320-channel level runs on a tile owning whole rows (80 x 320) and writes LayerNorm(out) next to out, so the
+# next sub-layer's norm needs no launch and does not re-read the stream.  DD_LN_PRODUCER=0 turns it off.
+LN_PRODUCER = __import__("os").environ.get("DD_LN_PRODUCER", "1") != "0"
+
+
+def ln_producer_ok(lin, norm, kw):
+    if not LN_PRODUCER or not isinstance(norm, LayerNorm) or lin.out_features != 320 or lin.fp8:
+        return False
+    if lin.w2d.shape[1] % 64 or kw.get("a2") is not None and kw["a2"].shape[1] % 64:
+        return False
+    bad = ("ln", "ln_direct", "ln_stats", "head_major", "out_f32", "accumulate", "rowvec", "out", "tile", "split_k")
+    return not any(kw.get(k) for k in bad) and kw.get("epilogue", O.DD_EPI_NONE) == O.DD_EPI_NONE \
+        and kw.get("alpha", 1.0) == 1.0
 
 
 def ln_direct_ok(norm, k, n, kw=None):
@@ -467,7 +493,7 @@ class Attention(_Cached):
         """K and V of the context in one GEMM -> (rows_ctx, 2*inner)."""
         return O.gemm(ctx2d, self._fused(("to_k", "to_v")), self._fused_bias(("to_k", "to_v")))
 
-    def run_self(self, x2d, batch, lq, res=None, norm=None, ln_stats=False):
+    def run_self(self, x2d, batch, lq, res=None, norm=None, ln_stats=False, ln_next=None):
         c, hd = self.inner_dim, self.heads
         if HEAD_MAJOR and self.to_q.bias is None:
             # Q | K | V written as one contiguous [rows][D] plane per head by the projection's epilogue: the
@@ -479,9 +505,9 @@ class Attention(_Cached):
             qkv = self.project_qkv(x2d, norm)
             o = O.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], batch, lq, lq, hd,
                             self.dim_head, self.scale)
-        return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
+        return self.to_out[0].run(o, res=res, ln_stats=ln_stats, ln_next=ln_next)
 
-    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None, ln_stats=False):
+    def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None, ln_stats=False, ln_next=None):
         c = self.inner_dim
         q_hm = HEAD_MAJOR and self.to_q.bias is None
         kw = {"head_major": self._hm(self.heads)} if q_hm else {}
@@ -497,7 +523,7 @@ class Attention(_Cached):
             kv = self.project_kv(ctx2d)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale,
                         q_prescaled=q_hm)
-        return self.to_out[0].run(o, res=res, ln_stats=ln_stats)
+        return self.to_out[0].run(o, res=res, ln_stats=ln_stats, ln_next=ln_next)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
@@ -583,22 +609,22 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def _attn(self, attn, norm, h, batch, l, ctx=None, lc=0, ln_next=True):
+    def _attn(self, attn, norm, h, batch, l, ctx=None, lc=0, ln_next=True, next_norm=None):
         """LayerNorm `norm` + `attn` (+ residual h).  The built-in processor folds the LayerNorm
         into the Q(KV) projection and the residual into the out-projection; foreign processors get
         the normalised (B, L, C) tensor through the diffusers protocol."""
         if isinstance(attn.processor, HIPAttnProcessor) and not getattr(attn.processor, "chunked", False):
             st = ln_next and want_ln_stats()          # the output feeds the block's next LayerNorm
             if ctx is None:
-                return attn.run_self(h, batch, l, res=h, norm=norm, ln_stats=st)
-            return attn.run_cross(h, batch, l, ctx, lc, res=h, norm=norm, ln_stats=st)
+                return attn.run_self(h, batch, l, res=h, norm=norm, ln_stats=st, ln_next=next_norm)
+            return attn.run_cross(h, batch, l, ctx, lc, res=h, norm=norm, ln_stats=st, ln_next=next_norm)
         e = None if ctx is None else ctx.reshape(batch, lc, -1)
         out = attn(norm.run(h).reshape(batch, l, -1), encoder_hidden_states=e)
         return O.add(out.reshape(batch * l, -1).contiguous(), h)
 
     def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
-        h = self._attn(self.attn1, self.norm1, h, batch, l)
-        h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc)
+        h = self._attn(self.attn1, self.norm1, h, batch, l, next_norm=self.norm2)
+        h = self._attn(self.attn2, self.norm2, h, batch, l, ctx2d, lc, next_norm=self.norm3)
         if defer_ff_out:                   # -> (gated hidden, residual): see Transformer2DModel.run
             return self.ff.run(h, norm=self.norm3, defer_out=True), h
         return self.ff.run(h, res=h, norm=self.norm3)
@@ -640,7 +666,7 @@ class Transformer2DModel(nn.Module):
 
     def run(self, x, m, h, w, ctx2d, lc):
         a = self.norm.run(x, m, h * w, False)
-        t = self.proj_in.run(a, ln_stats=want_ln_stats())
+        t = self.proj_in.run(a, ln_stats=want_ln_stats(), ln_next=getattr(self.transformer_blocks[0], "norm1", None))
         blocks = self.transformer_blocks
         if self.fold_proj_out and len(blocks) == 1 and isinstance(getattr(blocks[0], "ff", None), FeedForward):
             g, hres = blocks[0].run(t, m, h * w, ctx2d, lc, defer_ff_out=True)

@@ -322,7 +322,7 @@ def _rows2d(t):
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
          out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
-         ln_stats=False, head_major=None, ln_direct=None, w_scale=None):
+         ln_stats=False, head_major=None, ln_direct=None, w_scale=None, ln_out=None):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
     head_major = (D, scaled_planes, scale): the result comes back as (n / D, rows, D) — one contiguous
     [rows][D] plane per head of a fused Q|K|V projection, the first `scaled_planes` planes multiplied by
@@ -330,6 +330,9 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     out_f32: the result is stored as fp32 (attention logits that feed a softmax).
     ln_stats: the epilogue also leaves per-row partial sums of the output (n % 32 == 0) as `out._ln_stats`;
     a later gemm(out, ..., ln=...) picks them up instead of recomputing the row statistics.
+
+    ln_out = (gamma, beta, eps) (n == 320 only): the epilogue ALSO writes LayerNorm(out) — returned as the
+    attribute `out._ln_out` — from a tile that owns whole rows (tile 40, 80 x 320).
 
     w_scale (fp32 [n]) with `w` a torch.float8_e4m3fn [n, k] matrix: fp8 WEIGHTS with per-output-channel scales
     (extension, quantize_fp8()); row-panel shapes only (rowpanel_ok()).
@@ -414,6 +417,17 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         if g_.dtype != a.dtype or b_.dtype != a.dtype or g_.numel() != k or b_.numel() != k:
             raise ValueError("ln_direct gamma / beta must be %s vectors of %d entries" % (a.dtype, k))
         d.ln_gamma, d.ln_beta, d.ln_eps = g_.data_ptr(), b_.data_ptr(), float(eps_)
+    ln_second = None
+    if ln_out is not None:
+        g_, b_, eps_ = ln_out
+        _need_gpu(g_, b_)
+        if n != 320 or g_.numel() != n or b_.numel() != n or g_.dtype != a.dtype or b_.dtype != a.dtype:
+            raise ValueError("ln_out needs n == 320 and %s gamma / beta of 320 entries" % a.dtype)
+        ln_second = torch.empty((rows, n), dtype=a.dtype, device=a.device)
+        d.ln_out, d.ld_ln_out = ln_second.data_ptr(), n
+        d.lno_gamma, d.lno_beta, d.ln_eps = g_.data_ptr(), b_.data_ptr(), float(eps_)
+        d.tile, d.split_k = 40, 1
+        tile = 40
     stats_out = None
     if ln_stats:
         if n % 32 or epilogue == DD_EPI_GEGLU or out_f32:
@@ -440,6 +454,8 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "gemm")
     if stats_out is not None:
         out._ln_stats = stats_out
+    if ln_second is not None:
+        out._ln_out = ln_second
     return hm_out if hm_out is not None else out
 
 

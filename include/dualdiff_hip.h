@@ -157,6 +157,15 @@ typedef struct dd_gemm_desc {
    * 1 = the partial-slab launch only, 2 = the reduce launch only — so that a profiler-less caller (bench.py's
    * HIP-event brackets) can time the two kernels separately.  Ignored when split-K is off. */
   int32_t phase;
+  /* LayerNorm EMITTED BY THE EPILOGUE (dense mode, n == 320, tile 40 = 80 whole rows x 320 columns per workgroup):
+   * besides out = alpha * (A W^T + bias) + res, the kernel writes ln_out = LayerNorm(out) * lno_gamma + lno_beta
+   * (two-pass fp32 statistics over the values as ROUNDED to the storage type, eps = ln_eps) — the producer of the
+   * transformer's residual stream hands the next sub-layer its normalised input, so norm1 / norm2 / norm3 / norm4
+   * of the 28x50 level (networks/blocks.py:150-236) need no launch of their own.  ln_out: T [rows][ld_ln_out]. */
+  void* ln_out;            /* NULL = off */
+  int64_t ld_ln_out;
+  const void* lno_gamma;
+  const void* lno_beta;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);

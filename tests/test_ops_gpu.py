@@ -158,6 +158,29 @@ def test_gemm_rowpanel_fp8_weights(ops, dtype, tile, rows, n, k):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,k", [(16800, 320), (1400 * 2 + 37, 320), (80, 1600), (7, 64)])
+def test_gemm_layernorm_emitting_epilogue(ops, dtype, rows, k):
+    """Tile 40 (80 whole rows x 320 columns per workgroup): the epilogue stores out = A W^T + bias + res AND
+    LayerNorm(out) (statistics over the stored, rounded values) — both must match GEMM followed by LayerNorm."""
+    a = rnd((rows, k), dtype, 1)
+    w = rnd((320, k), dtype, 2, k ** -0.5)
+    b = rnd((320,), dtype, 3)
+    res = rnd((rows, 320), dtype, 4) * 3
+    g = rnd((320,), dtype, 5) + 1.0
+    be = rnd((320,), dtype, 6)
+    y = ops.gemm(a, w, b, res=res, ln_out=(g, be, 1e-5))
+    ref = L.linear_ref(a, w, b, res=res)
+    check(y, ref, dtype, "ln-emitting gemm: out %dx320x%d" % (rows, k))
+    # LayerNorm of the kernel's OWN stored output (isolates the fused normalisation from the GEMM rounding)
+    want = L.layernorm_ref(y, g, be)
+    check(y._ln_out, want, dtype, "ln-emitting gemm: LayerNorm(out)", 2.0)
+    y2 = ops.gemm(a, w, None, ln_out=(g, be, 1e-5))               # proj_in form: no residual, no bias
+    check(y2._ln_out, L.layernorm_ref(y2, g, be), dtype, "ln-emitting gemm (plain): LayerNorm(out)", 2.0)
+    # the tile is also a plain tile
+    check(ops.gemm(a, w, b, res=res, tile=40), ref, dtype, "tile 40 plain")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogue_full(ops, dtype):
     rows, n, k = 12 * 91, 640, 1280
     a = rnd((rows, 768), dtype, 1)
