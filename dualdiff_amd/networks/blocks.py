@@ -24,38 +24,65 @@ def _ensure_kv_is_int(view_pair):
     return {int(k): [int(x) for x in v] for k, v in view_pair.items()}
 
 
+class GatedConnector(nn.Module):
+    """tanh(alpha) * x with a zero-initialised per-channel alpha (blocks.py:24-32); on the HIP path the gate is
+    folded into the out-projection weights like the Linear connector."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.zeros(dim))
+
+
 class BasicMultiviewTransformerBlock(BasicTransformerBlock):
     def __init__(self, dim, num_attention_heads, attention_head_dim, cross_attention_dim=None,
                  neighboring_view_pair=None, neighboring_attn_type="add", zero_module_type="zero_linear",
                  **unused):
         super().__init__(dim, num_attention_heads, attention_head_dim, cross_attention_dim=cross_attention_dim)
-        if neighboring_attn_type != "add" or zero_module_type != "zero_linear":
-            raise NotImplementedError("only neighboring_attn_type='add' / zero_linear connector "
-                                      "(configs/model/SDv1.5mv_rawbox.yaml:19-21)")
+        if neighboring_attn_type not in ("add", "concat", "self"):
+            raise NotImplementedError("Unknown type: %s" % neighboring_attn_type)          # blocks.py:140-142
         self.neighboring_view_pair = _ensure_kv_is_int(neighboring_view_pair)
         self.neighboring_attn_type = neighboring_attn_type
+        self.zero_module_type = zero_module_type
         self.norm4 = LayerNorm(dim)
         self.attn4 = Attention(dim, dim, num_attention_heads, attention_head_dim)
-        self.connector = Linear(dim, dim)
+        if zero_module_type == "zero_linear":                 # blocks.py:81-90
+            self.connector = Linear(dim, dim)
+        elif zero_module_type == "gated":
+            self.connector = GatedConnector(dim)
+        elif zero_module_type == "none":
+            self.connector = None
+        else:
+            raise TypeError("Unknown zero module type: %s" % zero_module_type)
         self._maps = {}
         # dualdiff_amd.parallel.ViewShard when the views of a scene are spread over several GPUs
         # (UNet2DConditionModelMultiview.set_view_shard); None = all n_cam views are local
         self.view_shard = None
 
-    # `connector(to_out(o))` is two Linear layers with nothing in between (blocks.py:203-222): they
-    # run as ONE GEMM with W = Wc Wo and b = Wc (nb b_o) + b_c, folded in fp32 when the weights change.
+    # `connector(to_out(o))` is two linear maps with nothing in between (blocks.py:203-222): they always run as
+    # ONE GEMM with folded weights (_folded_out).
     fold_connector = True
 
     def _folded_out(self, nb):
+        """(W, b) of `connector(sum of nb to_out applications)` as ONE Linear on the summed attention outputs:
+        zero_linear: W = Wc Wo, b = Wc (nb b_o) + b_c; gated: W = diag(tanh a) Wo, b = tanh(a) * nb b_o;
+        none: W = Wo, b = nb b_o.  Folded in fp32 whenever a parameter changes."""
         wo, bo = self.attn4.to_out[0].weight, self.attn4.to_out[0].bias
-        wc, bc = self.connector.weight, self.connector.bias
-        key = (nb, wo._version, bo._version, wc._version, bc._version, wo.data_ptr(), wc.data_ptr())
-        hit = self.connector.__dict__.get("_pk_fold")
+        cp = [] if self.connector is None else list(self.connector.parameters())
+        key = (nb, wo._version, bo._version, wo.data_ptr()) + tuple((t._version, t.data_ptr()) for t in cp)
+        holder = self.attn4.to_out[0].__dict__
+        hit = holder.get("_pk_fold")
         if hit is None or hit[0] != key:
             with torch.no_grad():
-                w = (wc.detach().float() @ wo.detach().float()).to(wo.dtype).contiguous()
-                b = (wc.detach().float() @ (bo.detach().float() * nb) + bc.detach().float()).to(wo.dtype).contiguous()
-            hit = self.connector.__dict__["_pk_fold"] = (key, w, b)
+                wof, bof = wo.detach().float(), bo.detach().float() * nb
+                if self.zero_module_type == "zero_linear":
+                    wc, bc = self.connector.weight.detach().float(), self.connector.bias.detach().float()
+                    w, b = wc @ wof, wc @ bof + bc
+                elif self.zero_module_type == "gated":
+                    g = torch.tanh(self.connector.alpha.detach().float())
+                    w, b = g[:, None] * wof, g * bof
+                else:
+                    w, b = wof, bof
+                hit = holder["_pk_fold"] = (key, w.to(wo.dtype).contiguous(), b.to(wo.dtype).contiguous())
         return hit[1], hit[2]
 
     @property
@@ -64,7 +91,10 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
 
     @property
     def new_module(self):
-        return {"norm4": self.norm4, "attn4": self.attn4, "connector": self.connector}
+        ret = {"norm4": self.norm4, "attn4": self.attn4}
+        if self.connector is not None:
+            ret["connector"] = self.connector
+        return ret
 
     def neighbour_maps(self, batch, device):
         """int32 [batch] maps: instance b*n_cam+v -> instance of its k-th neighbour."""
@@ -108,10 +138,40 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         return o, len(maps)
 
     def _cross_view(self, h, batch, l):
-        """norm4 -> attn4 over the neighbour views -> connector -> + h (blocks.py:190-222)."""
+        """norm4 -> attn4 over the neighbour views -> connector -> + h (blocks.py:106-142,190-222)."""
         a = self.attn4
-        c = a.inner_dim
-        if self.view_shard is not None:
+        c, hd, d = a.inner_dim, a.heads, a.dim_head
+        kind = self.neighboring_attn_type
+        if kind != "add" and not (layers.HEAD_MAJOR and a.to_q.bias is None):
+            raise NotImplementedError("neighboring_attn_type='%s' needs the head-major bias-free projection" % kind)
+        if kind == "self":                            # :135-139: ONE self-attention over all views of a scene
+            if self.view_shard is not None:
+                raise NotImplementedError("neighboring_attn_type='self' attends to every view: not view-shardable")
+            qkv = a.project_qkv(h, self.norm4, head_major=True)
+            o = O.attention(qkv[:hd], qkv[hd:2 * hd], qkv[2 * hd:], batch // self.n_cam, self.n_cam * l,
+                            self.n_cam * l, hd, d, q_prescaled=True)
+            nb = 1
+        elif kind == "concat":                        # :122-134: the neighbours' tokens as ONE key sequence
+            qkv = a.project_qkv(h, self.norm4, head_major=True)
+            if self.view_shard is not None:
+                sh = self.view_shard
+                nloc = sh.n_local
+                nbat = batch // nloc
+                kv = torch.empty((sh.plan.n_slots, nbat, 2 * hd, l, d), dtype=h.dtype, device=h.device)
+                kv[:nloc].copy_(qkv[hd:].reshape(2 * hd, nbat, nloc, l, d).permute(2, 1, 0, 3, 4))
+                sh.exchange(kv)
+                src = kv.reshape(sh.plan.n_slots * nbat, 2 * hd, l, d)
+                maps = sh.maps(nbat, h.device)
+            else:
+                src = qkv[hd:].reshape(2 * hd, batch, l, d).permute(1, 0, 2, 3)      # (instance, 2 hd, l, d) view
+                maps = self.neighbour_maps(batch, h.device)
+            cat = torch.empty((batch, 2 * hd, len(maps), l, d), dtype=h.dtype, device=h.device)
+            for j, mp in enumerate(maps):
+                cat[:, :, j] = src.index_select(0, mp.long())
+            cat = cat.reshape(batch, 2 * hd, len(maps) * l, d)
+            o = O.attention(qkv[:hd], cat[:, :hd], cat[:, hd:], batch, l, len(maps) * l, hd, d, q_prescaled=True)
+            nb = 1
+        elif self.view_shard is not None:
             o, nb = self._attn4_sharded(h, batch, l)
         else:
             hm = layers.HEAD_MAJOR and a.to_q.bias is None
@@ -124,17 +184,13 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
                 o = O.attention(q, k, v, batch, l, l, a.heads, a.dim_head, a.scale, kv_batch_map=mp, out=o,
                                 accumulate=j > 0, q_prescaled=hm)
             nb = len(maps)
-        if self.fold_connector:
-            w, b = self._folded_out(nb)
-            if layers.LN_PRODUCER and w.shape[0] == 320 and not want_ln_stats():   # emits norm3(out) as well
-                out = O.gemm(o, w, b, res=h, ln_out=(self.norm3.weight, self.norm3.bias, self.norm3.eps))
-                out._ln_cache = (self.norm3, out._ln_out)
-                return out
-            return O.gemm(o, w, b, res=h, ln_stats=want_ln_stats())        # feeds norm3
-        if "_pk_bias_nb" not in a.__dict__ or a.__dict__["_pk_bias_nb"][0] != nb:
-            a.__dict__["_pk_bias_nb"] = (nb, (a.to_out[0].bias.detach().float() * nb).to(a.to_out[0].bias.dtype))
-        y = O.gemm(o, a.to_out[0].w2d, a.__dict__["_pk_bias_nb"][1])
-        return self.connector.run(y, res=h, ln_stats=want_ln_stats())
+        # connector(to_out(...)) as one GEMM with the residual add (folded weights, see _folded_out)
+        w, b = self._folded_out(nb)
+        if layers.LN_PRODUCER and w.shape[0] == 320 and not want_ln_stats():       # emits norm3(out) as well
+            out = O.gemm(o, w, b, res=h, ln_out=(self.norm3.weight, self.norm3.bias, self.norm3.eps))
+            out._ln_cache = (self.norm3, out._ln_out)
+            return out
+        return O.gemm(o, w, b, res=h, ln_stats=want_ln_stats())        # feeds norm3
 
     def run(self, h, batch, l, ctx2d, lc, defer_ff_out=False):
         h = self._attn(self.attn1, self.norm1, h, batch, l, next_norm=self.norm2)

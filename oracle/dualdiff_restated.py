@@ -208,21 +208,41 @@ def box_adapter(net):
 
 
 # -------------------------------------------------------------- multiview block (A4, A6) --
+class GatedConnector(nn.Module):
+    """networks/blocks.py:24-32: tanh(alpha) * x with a zero-initialised per-channel alpha."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return torch.tanh(self.alpha) * x
+
+
 class BasicMultiviewTransformerBlock(D.BasicTransformerBlock):
-    """networks/blocks.py:35-238 with neighboring_attn_type='add', zero_module_type='zero_linear'.
-    attn4: for view v and each neighbour u in pair[v]: to_out(Attn(Wq x_v, Wk x_u, Wv x_u)) — the
-    out-projection (with its bias) is applied per pair and the pairs are summed (:203-217) —
-    then connector Linear and residual (:220-222)."""
+    """networks/blocks.py:35-238.  neighboring_attn_type (:106-142): 'add' — for view v and each neighbour u in
+    pair[v]: to_out(Attn(Wq x_v, Wk x_u, Wv x_u)), the out-projection (with its bias) applied per pair and the
+    pairs summed (:203-217); 'concat' — one attention of view v over the concatenated tokens of its neighbours;
+    'self' — one self-attention over the tokens of ALL views of a scene.  zero_module_type (:81-90):
+    'zero_linear' Linear connector, 'gated' tanh(alpha) gate, 'none' identity.  Then residual (:220-222)."""
 
     def __init__(self, *args, neighboring_view_pair=None, neighboring_attn_type="add",
                  zero_module_type="zero_linear", **kw):
         super().__init__(*args, **kw)
-        assert neighboring_attn_type == "add" and zero_module_type == "zero_linear"
+        assert neighboring_attn_type in ("add", "concat", "self")
         dim, heads, hd = self._args["dim"], self._args["num_attention_heads"], self._args["attention_head_dim"]
         self.neighboring_view_pair = {int(k): [int(x) for x in v] for k, v in neighboring_view_pair.items()}
+        self.neighboring_attn_type = neighboring_attn_type
         self.norm4 = nn.LayerNorm(dim)
         self.attn4 = D.Attention(query_dim=dim, cross_attention_dim=dim, heads=heads, dim_head=hd)
-        self.connector = D.zero_module(nn.Linear(dim, dim))
+        if zero_module_type == "zero_linear":
+            self.connector = D.zero_module(nn.Linear(dim, dim))
+        elif zero_module_type == "gated":
+            self.connector = GatedConnector(dim)
+        elif zero_module_type == "none":
+            self.connector = lambda x: x
+        else:
+            raise TypeError(zero_module_type)
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None):
@@ -233,12 +253,21 @@ class BasicMultiviewTransformerBlock(D.BasicTransformerBlock):
         x = self.norm4(h)
         xv = x.reshape(-1, n_cam, x.shape[1], x.shape[2])          # (b, view, tokens, C)
         a = self.attn4
-        q, k, v = a.to_q(xv), a.to_k(xv), a.to_v(xv)
-        out = torch.zeros_like(xv)
-        for view, neighbours in self.neighboring_view_pair.items():
-            for u in neighbours:
-                o = sdpa(q[:, view], k[:, u], v[:, u], a.heads, a.scale)
-                out[:, view] = stor(out[:, view] + a.to_out[0](o))
+        if self.neighboring_attn_type == "self":                     # :135-139: all views in one sequence
+            xs = xv.reshape(xv.shape[0], n_cam * xv.shape[2], xv.shape[3])
+            out = a.to_out[0](sdpa(a.to_q(xs), a.to_k(xs), a.to_v(xs), a.heads, a.scale)).reshape_as(xv)
+        else:
+            q, k, v = a.to_q(xv), a.to_k(xv), a.to_v(xv)
+            out = torch.zeros_like(xv)
+            for view, neighbours in self.neighboring_view_pair.items():
+                if self.neighboring_attn_type == "concat":           # :122-134: keys of all neighbours together
+                    kc = torch.cat([k[:, u] for u in neighbours], dim=1)
+                    vc = torch.cat([v[:, u] for u in neighbours], dim=1)
+                    out[:, view] = a.to_out[0](sdpa(q[:, view], kc, vc, a.heads, a.scale))
+                    continue
+                for u in neighbours:
+                    o = sdpa(q[:, view], k[:, u], v[:, u], a.heads, a.scale)
+                    out[:, view] = stor(out[:, view] + a.to_out[0](o))
         h = stor(self.connector(out.reshape_as(x)) + h)
         return stor(self.ff(self.norm3(h)) + h)
 

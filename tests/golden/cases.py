@@ -227,3 +227,9 @@ def step_inputs(b=2):
 def step_latents():
     """(1, 6, 4, 28, 50): one draw replicated over the 6 views (pipeline_bev_controlnet.py:345)."""
     return bf16_round(seeded_tensor((1, 4, H, W), SEED_STEP_LAT))[:, None].expand(-1, N_CAM, -1, -1, -1).contiguous()
+
+
+# variants of the multiview block the reference also defines (blocks.py:81-90,106-142): golden fixture
+# multiview_block_variants.npz (tests/golden/mint.py variants)
+BLOCK_VARIANTS = (("concat", "zero_linear"), ("self", "zero_linear"), ("add", "gated"), ("add", "none"))
+SEED_BLOCK_VAR = 25

@@ -100,6 +100,26 @@ def load_from(ref_module, oracle_module, seed):
 
 
 @torch.no_grad()
+def mint_block_variants():
+    """`python tests/golden/mint.py variants`: the reference's BasicMultiviewTransformerBlock with the other
+    neighboring_attn_type / zero_module_type settings it defines (level 2: its control flow over restated leaves)."""
+    install_stubs()
+    from oracle import dualdiff_restated as R
+    from magicdrive.networks import blocks as ref_blocks
+    kw = C.block_kwargs()
+    hs, ctx = C.block_inputs()
+    out = {}
+    for attn_type, zero_type in C.BLOCK_VARIANTS:
+        ref = ref_blocks.BasicMultiviewTransformerBlock(**kw, neighboring_view_pair=C.VIEW_PAIR,
+                                                        neighboring_attn_type=attn_type, zero_module_type=zero_type)
+        load_from(ref, R.BasicMultiviewTransformerBlock(**kw, neighboring_view_pair=C.VIEW_PAIR,
+                                                        neighboring_attn_type=attn_type, zero_module_type=zero_type),
+                  C.SEED_BLOCK_VAR)
+        out["%s_%s" % (attn_type, zero_type)] = ref(hs, encoder_hidden_states=ctx)
+    save("multiview_block_variants", **out)
+
+
+@torch.no_grad()
 def main():
     install_stubs()
     from oracle import dualdiff_restated as R
@@ -259,6 +279,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ors":
         install_stubs()
         mint_ors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "variants":
+        mint_block_variants()
     else:
         main()
         mint_ors()
+        mint_block_variants()

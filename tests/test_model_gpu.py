@@ -423,3 +423,51 @@ def test_multiview_block_standalone(gpu, dtype):
         y = blk.run(x.cuda().to(dtype).reshape(-1, 640), 6, 350, ctx.cuda().to(dtype).reshape(-1, 768), 30)
     rec = []
     assert report("multiview block standalone", y.reshape(6, 350, 640), ref, dtype, rec, emul) <= 1.0, rec
+
+
+def _variant_pair(attn_type, zero_type, seed=7):
+    """(oracle block, state dict, inputs) of one neighboring_attn_type / zero_module_type setting at the L1 shape."""
+    ora = R.BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR,
+                                           neighboring_attn_type=attn_type, zero_module_type=zero_type).eval()
+    sd = {k: bf16_round(v) for k, v in seeded_state_dict(ora, seed).items()}
+    ora.load_state_dict(sd)
+    return ora, sd, bf16_round(seeded_tensor((12, 350, 640), 3)), bf16_round(seeded_tensor((12, 30, 768), 4))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("attn_type,zero_type", [("concat", "zero_linear"), ("self", "zero_linear"),
+                                                 ("add", "gated"), ("add", "none"), ("concat", "gated")])
+def test_multiview_block_variants(gpu, attn_type, zero_type, dtype):
+    """The block's other settings (reference blocks.py:81-90 connector kinds, :106-142 neighbour attention kinds;
+    the oracle's restatement of them is pinned by tests/golden/multiview_block_variants.npz): 2 scenes x 6 views."""
+    from dualdiff_amd.networks.blocks import BasicMultiviewTransformerBlock
+    ora, sd, x, ctx = _variant_pair(attn_type, zero_type)
+    with torch.no_grad():
+        ref = ora(x, encoder_hidden_states=ctx)
+        with storage_emulation(ora, dtype):
+            emul = ora(x, encoder_hidden_states=ctx)
+        blk = BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR,
+                                             neighboring_attn_type=attn_type, zero_module_type=zero_type)
+        blk.load_state_dict(sd)
+        blk = blk.to("cuda", dtype)
+        y = blk.run(x.cuda().to(dtype).reshape(-1, 640), 12, 350, ctx.cuda().to(dtype).reshape(-1, 768), 30)
+    rec = []
+    name = "multiview block %s/%s" % (attn_type, zero_type)
+    assert report(name, y.reshape(12, 350, 640), ref, dtype, rec, emul) <= 1.0, rec
+    # the variant matters: the default block on the same weights gives a different answer
+    if attn_type != "add":
+        base = R.BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR,
+                                                zero_module_type=zero_type).eval()
+        base.load_state_dict(sd)
+        with torch.no_grad():
+            assert rel_l2(base(x, encoder_hidden_states=ctx), ref) > 1e-2
+
+
+def test_multiview_block_unknown_variant_raises(gpu):
+    from dualdiff_amd.networks.blocks import BasicMultiviewTransformerBlock
+    with pytest.raises(NotImplementedError):                 # blocks.py:140-142
+        BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR,
+                                       neighboring_attn_type="ring")
+    with pytest.raises(TypeError):                           # blocks.py:89-90
+        BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR,
+                                       zero_module_type="relu")

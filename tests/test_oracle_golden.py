@@ -76,6 +76,19 @@ def test_multiview_block():
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("attn_type,zero_type", C.BLOCK_VARIANTS)
+def test_multiview_block_variants(attn_type, zero_type):
+    """The block's other neighboring_attn_type / zero_module_type settings (blocks.py:81-90,106-142) against the
+    reference's own block executed on the same seeded weights."""
+    m = seeded_init_(R.BasicMultiviewTransformerBlock(**C.block_kwargs(), neighboring_view_pair=C.VIEW_PAIR,
+                                                      neighboring_attn_type=attn_type, zero_module_type=zero_type),
+                     C.SEED_BLOCK_VAR)
+    hs, ctx = C.block_inputs()
+    C.compare(gold("multiview_block_variants"), "%s_%s" % (attn_type, zero_type),
+              m(hs, encoder_hidden_states=ctx), RTOL, ATOL)
+
+
+@torch.no_grad()
 def test_unet_multiview():
     m = seeded_init_(R.UNet2DConditionModelMultiview(**C.unet_kwargs(), neighboring_view_pair=C.VIEW_PAIR),
                      C.SEED_UNET).eval()

@@ -416,3 +416,62 @@ def test_view_split_denoiser_one_gpu(step_models, shards):
     assert e <= 2e-3
     # the halo matters: every shard's result depends on views it does not own
     assert all(p.remote for p in plans)
+
+
+@pytest.mark.parametrize("attn_type", ["add", "concat"])
+def test_view_split_block_variants_one_gpu(gpu, attn_type):
+    """One multiview block with its 6 views spread over 2 shards (threads, one stream each): the 'add' and the
+    'concat' neighbour attention fetch the remote views' K/V through the same slot buffer and reproduce the
+    unsharded block; 'self' attends to every view and refuses to shard."""
+    import threading
+    from dualdiff_amd.networks.blocks import BasicMultiviewTransformerBlock
+    from dualdiff_amd.parallel import ViewShard, ViewSplitPlan
+    from oracle.init_utils import seeded_state_dict, seeded_tensor
+    dtype, nb, l = torch.float16, 2, 350
+    kw = dict(cross_attention_dim=768, neighboring_view_pair=PAIR, neighboring_attn_type=attn_type)
+    ora = R.BasicMultiviewTransformerBlock(640, 8, 80, **kw)
+    sd = seeded_state_dict(ora, 11)
+    x = seeded_tensor((nb, 6, l, 640), 5).cuda().to(dtype)
+    ctx = seeded_tensor((nb, 6, 30, 768), 6).cuda().to(dtype)
+
+    def make():
+        blk = BasicMultiviewTransformerBlock(640, 8, 80, **kw)
+        blk.load_state_dict(sd)
+        return blk.to("cuda", dtype)
+
+    with torch.no_grad():
+        want = make().run(x.reshape(-1, 640), nb * 6, l, ctx.reshape(-1, 768), 30).reshape(nb, 6, l, 640).float().cpu()
+    plans = [ViewSplitPlan(2, r, PAIR, cfg_split=False) for r in range(2)]
+    ex = _LocalExchange(plans)
+    outs, errs = {}, []
+
+    def work(p):
+        try:
+            with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream()):
+                blk = make()
+                blk.view_shard = ViewShard(p, ex.bind(p))
+                xs, cs = x[:, p.local].contiguous(), ctx[:, p.local].contiguous()
+                n = nb * len(p.local)
+                outs[p.shard] = blk.run(xs.reshape(-1, 640), n, l, cs.reshape(-1, 768), 30) \
+                    .reshape(nb, len(p.local), l, 640).float().cpu()
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+            ex.barrier.abort()
+
+    torch.cuda.synchronize()
+    ths = [threading.Thread(target=work, args=(p,)) for p in plans]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    got = torch.cat([outs[p.shard] for p in plans], dim=1)
+    e = rel_l2(got, want)
+    print("view split block (%s): vs unsharded rel-L2 %.3e" % (attn_type, e))
+    log_row("view split x2 block %s vs unsharded" % attn_type, dtype, e, 0.0, 1e-3)
+    assert e <= 1e-3
+    blk = make()
+    blk.neighboring_attn_type = "self"
+    blk.view_shard = ViewShard(plans[0], ex.bind(plans[0]))
+    with pytest.raises(NotImplementedError):
+        blk.run(x[:, plans[0].local].reshape(-1, 640), nb * 3, l, ctx[:, plans[0].local].reshape(-1, 768), 30)
