@@ -20,8 +20,15 @@ template <typename T> struct dd_vec;
 template <> struct dd_vec<_Float16> { using v8 = f16x8; using v4 = f16x4; };
 template <> struct dd_vec<__bf16>   { using v8 = bf16x8; using v4 = bf16x4; };
 
+// DD_DBG_NOMFMA / DD_DBG_NODMA (tools/build_dbg_libs.sh): diagnostic builds that drop one side of the main loop
+// (matrix instructions, or the LDS-DMA loads) to see which one bounds a kernel.  Never defined in the product build.
 __device__ __forceinline__ f32x4 dd_mfma16(f16x8 a, f16x8 b, f32x4 c) {
+#ifdef DD_DBG_NOMFMA
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f32x4 dd_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);

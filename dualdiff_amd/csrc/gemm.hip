@@ -47,6 +47,7 @@ struct GemmParams {
   const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
   const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
   int no_stagger;                        // conv3s A/B switch (DD_STAGGER=0)
+  uint64_t* dbg_stamps;                  // DD_DBG_STAMP builds only
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
   void* ln_out; int64_t ld_ln_out;       // LayerNorm EMITTED by the epilogue of the 80x320 tile (second output)
   const void* lno_gamma; const void* lno_beta;
@@ -668,12 +669,23 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // offset.  An offset outside the descriptor's range reads zeros (hardware range check), which is how
 // padding taps and tile tails are produced — no 64-bit pointer arithmetic, no select against a zero page.
 __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+#ifndef DD_DBG_NODMA
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
                                            (int)voff, (int)soff, 0, 0);
+#endif
 }
 // every buffer is < 2^31 bytes (checked on the host), so this lane offset is out of range whatever
 // scalar offset is added to it
 constexpr uint32_t DD_OOB = 0x80000000u;
+
+// DD_DBG_STAMP (diagnostic build only, tools/build_dbg_libs.sh): wave 0 of every workgroup of the direct conv records
+// s_memtime at phase boundaries plus s_memrealtime at both ends into the LAST MiB of the workspace (ops.py over-allocates
+// it when DD_DBG_STAMP_WS=1); nothing reads them on the device.
+#ifdef DD_DBG_STAMP
+#define DD_STAMP(i) do { if (threadIdx.x == 0) dbg_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DD_STAMP(i) do {} while (0)
+#endif
 
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
@@ -693,6 +705,11 @@ void dd_gemm2_kernel(const GemmParams p) {
   static_assert(NSTAGE >= 2 && NSTAGE <= 8, "NSTAGE");
   static_assert((NSTAGE - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
 
+#ifdef DD_DBG_STAMP
+  uint64_t dbg_t[6];
+  const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  DD_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);
 
@@ -818,7 +835,11 @@ void dd_gemm2_kernel(const GemmParams p) {
   auto issue_next = [&](int slot) __attribute__((always_inline)) {
     T* xs = ring + slot * STAGE;
     T* ws = xs + BM * BK;
+#ifdef DD_DBG_SAMEK      // diagnostic: every K-step re-stages the SAME bytes (L1-resident after the first step)
+    const uint32_t ksoff = 0u;
+#else
     const uint32_t ksoff = (uint32_t)ik0 * 2u;
+#endif
 #pragma unroll
     for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], ksoff, ws + (j * NW + wave) * 8 * BK);
     if (CONV) {
@@ -852,9 +873,11 @@ void dd_gemm2_kernel(const GemmParams p) {
   const int fswz = (lane >> 1) & 7;
   const int fchunk = lane >> 4;
 
+  DD_STAMP(1);
 #pragma unroll
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
     if (s0 < nk) issue_next(s0);
+  DD_STAMP(2);
 
   // LayerNorm fold: row statistics of the block's A rows (K = 40 * lpr columns: lpr lanes share a
   // row, five 16-B vectors per lane), computed while the first stages are in flight.
@@ -971,8 +994,12 @@ void dd_gemm2_kernel(const GemmParams p) {
   };
   for (int kt = 0; kt < nk; kt += 2) {
     kstep(kt, std::integral_constant<int, 0>{});
+#ifdef DD_DBG_STAMP
+    if (kt == 0) DD_STAMP(3);                  // after the first K-step
+#endif
     if (kt + 1 < nk) kstep(kt + 1, std::integral_constant<int, 1>{});
   }
+  DD_STAMP(4);
   if constexpr (STAG) {
     if (late && nk > 0) {                  // the last K-step's MFMAs of the staggered waves
       if ((nk - 1) & 1) mfma_step(std::integral_constant<int, 1>{});
@@ -988,6 +1015,15 @@ void dd_gemm2_kernel(const GemmParams p) {
   const bool ln = !CONV && p.ln_colsum;
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
                                ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr, tile);
+#ifdef DD_DBG_STAMP
+  DD_STAMP(5);
+  if (threadIdx.x == 0 && p.dbg_stamps) {
+    uint64_t* o = p.dbg_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
+    o[6] = dbg_r0;
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // =============================================================================================
@@ -1020,6 +1056,11 @@ void dd_conv3s_kernel(const GemmParams p) {
   static_assert(TN % 2 == 0, "TN");
   static_assert(NSW >= 3 && NSW <= 10 && (NSW - 2) * WI + XA <= 63, "ring depth / vmcnt");
 
+#ifdef DD_DBG_STAMP
+  uint64_t dbg_t[6];
+  const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  DD_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* abuf = reinterpret_cast<T*>(smem);                 // [2][AROWS][64]
   T* wring = abuf + 2 * AROWS * BK;                     // [NSW][BN][64]
@@ -1076,6 +1117,42 @@ void dd_conv3s_kernel(const GemmParams p) {
     const int col = block_n0 + wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
     wv[j] = col < p.n ? (uint32_t)col * (uint32_t)p.k * 2u + lcb : DD_OOB;
   }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+
+  auto issue_a = [&](int c) __attribute__((always_inline)) {           // chunk c (local index) -> abuf[c & 1]
+    T* dst = abuf + (c & 1) * AROWS * BK;
+    const uint32_t so = (uint32_t)((c_beg + c) * BK) * 2u;
+#pragma unroll
+    for (int j = 0; j < XA; ++j) bdma16(rs_a, av[j], so, dst + (j * NW + wave) * 8 * BK);
+  };
+  auto issue_w = [&](int c, int t, int slot) __attribute__((always_inline)) {
+    T* dst = wring + slot * BN * BK;
+    const uint32_t so = (uint32_t)(t * p.cin + (c_beg + c) * BK) * 2u;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], so, dst + (j * NW + wave) * 8 * BK);
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fswz = (lane >> 1) & 7;
+  const int fchunk = lane >> 4;
+
+  DD_STAMP(1);
+  if (nc > 0) {
+    issue_a(0);
+#pragma unroll
+    for (int s0 = 0; s0 < (GRP == 1 ? NSW - 1 : NSW); ++s0)
+      if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0);
+  }
+  DD_STAMP(2);
+  // (built AFTER the prologue DMAs are in flight: ~60 entries x ~20 VALU instructions took 3.7 us of a 36 us
+  //  kernel in front of the first load; now they run under the 2-3 us the cold weights need to arrive)
   // ---- per-lane tap tables: LDS row of the pixel each tap reads (BM = the zero row), 2 x 16 bit
   uint32_t tab[TM][5];
 #pragma unroll
@@ -1110,38 +1187,6 @@ void dd_conv3s_kernel(const GemmParams p) {
       }
       tab[tm][t2] = packed;
     }
-  }
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
-
-  auto issue_a = [&](int c) __attribute__((always_inline)) {           // chunk c (local index) -> abuf[c & 1]
-    T* dst = abuf + (c & 1) * AROWS * BK;
-    const uint32_t so = (uint32_t)((c_beg + c) * BK) * 2u;
-#pragma unroll
-    for (int j = 0; j < XA; ++j) bdma16(rs_a, av[j], so, dst + (j * NW + wave) * 8 * BK);
-  };
-  auto issue_w = [&](int c, int t, int slot) __attribute__((always_inline)) {
-    T* dst = wring + slot * BN * BK;
-    const uint32_t so = (uint32_t)(t * p.cin + (c_beg + c) * BK) * 2u;
-#pragma unroll
-    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], so, dst + (j * NW + wave) * 8 * BK);
-  };
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15;
-  const int fswz = (lane >> 1) & 7;
-  const int fchunk = lane >> 4;
-
-  if (nc > 0) {
-    issue_a(0);
-#pragma unroll
-    for (int s0 = 0; s0 < (GRP == 1 ? NSW - 1 : NSW); ++s0)
-      if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0);
   }
   int wslot = 0;                                        // ring slot of step s (scalar)
   // Gathered activation fragments are double-buffered across steps: while the MFMAs of tap t run,
@@ -1256,8 +1301,12 @@ void dd_conv3s_kernel(const GemmParams p) {
   };
   for (int c = 0; c < nc; c += 2) {
     chunk(c, std::integral_constant<int, 0>{});            // even chunk: tap t uses parity t & 1
+#ifdef DD_DBG_STAMP
+    if (c == 0) DD_STAMP(3);                               // after the first 9 steps
+#endif
     if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{});   // odd chunk: parity (t + 1) & 1
   }
+  DD_STAMP(4);
   if (late && nsteps > 0) {                               // staggered waves: the last step's MFMAs are still due
     auto drain = [&](auto par_c) __attribute__((always_inline)) {
       constexpr int par = decltype(par_c)::value;
@@ -1274,6 +1323,15 @@ void dd_conv3s_kernel(const GemmParams p) {
   // rows past the tile's instances are padding
   store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows),
                                nullptr, nullptr, tile);
+#ifdef DD_DBG_STAMP
+  DD_STAMP(5);
+  if (threadIdx.x == 0 && p.dbg_stamps) {
+    uint64_t* o = p.dbg_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
+    o[6] = dbg_r0;
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // =============================================================================================
@@ -1829,6 +1887,7 @@ template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool CONV, boo
 int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
+  static_assert(smem <= 160 * 1024, "LDS");
   auto kern = dd_gemm2_kernel<T, WM, WN, TM, TN, NSTAGE, CONV, GEGLU>;
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
@@ -2127,6 +2186,11 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   }
   p.partial = nullptr;
   p.tile_counters = nullptr;
+  p.dbg_stamps = nullptr;
+#ifdef DD_DBG_STAMP
+  if (d->ws && d->ws_bytes >= (4 << 20))
+    p.dbg_stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d->ws) + d->ws_bytes - (1 << 20));
+#endif
   if (pl.split > 1) {
     const int64_t need = DD_COUNTER_BYTES + (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
     if (!d->ws || d->ws_bytes < need) return DD_ERR_WORKSPACE;

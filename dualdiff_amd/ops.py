@@ -262,6 +262,10 @@ _WS_IN_GRAPH = set()      # keys whose current buffer a captured HIP graph holds
 _WS_RETIRED = []          # such buffers after they were outgrown: kept alive for the graphs that use them
 
 
+# diagnostic builds (-DDD_DBG_STAMP, tools/build_dbg_libs.sh) write phase stamps into the tail of the workspace
+_DBG_STAMP_WS = _os.environ.get("DD_DBG_STAMP_WS", "0") == "1"
+
+
 def workspace(nbytes, device, kind="gemm"):
     """Grow-only fp32 scratch buffer per (device, stream, kind): kernels on concurrent streams must
     not share scratch, and the split-K buffer (whose leading counter region dd_gemm keeps at zero)
@@ -445,7 +449,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
                                       + (("res",) if res is not None else ()) + (("acc",) if accumulate else ()),
                                       (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
-    if need > 0:
+    if need > 0 or _DBG_STAMP_WS:
         ws = workspace(need, a.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
     if _TIMER is not None:
@@ -505,7 +509,7 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
         d.tile, d.split_k = _autotune(lib, d, ("c", m, hin, win, cin, cout, stride, hv, wv, d.dtype),
                                       (rows, cout), x.dtype, x.device, warm=(x, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
-    if need > 0:
+    if need > 0 or _DBG_STAMP_WS:
         ws = workspace(need, x.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
     if _TIMER is not None:

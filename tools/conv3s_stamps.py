@@ -1,0 +1,37 @@
+"""DIAGNOSTIC (needs DD_HIP_LIB=<a library built with -DDD_DBG_STAMP>, tools/build_dbg_libs.sh): phase timeline of the
+direct small-image conv — per workgroup, cycles from kernel entry to: tables built, prologue DMAs issued, first 9 steps
+done, main loop done, tile stored; plus the in-kernel clock (s_memtime over s_memrealtime)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dualdiff_amd import ops as O
+dt = torch.float16
+dev = torch.device("cuda")
+O.workspace(512 << 20, dev)
+for (b, h, w, c) in ((12, 14, 25, 640), (12, 7, 13, 1280), (12, 4, 7, 1280)):
+    rows = b * h * w
+    x = (torch.randn(rows, c, device=dev)).to(dt)
+    wt = (torch.randn(c, 9 * c, device=dev) * (9 * c) ** -0.5).to(dt)
+    bi = torch.randn(c, device=dev).to(dt)
+    for _ in range(20):
+        O.conv3x3(x, wt, bi, b, h, w)
+    torch.cuda.synchronize()
+    ws = O.workspace(1, dev)
+    tail = ws.view(torch.int64)[-(1 << 17):].clone()
+    tail.zero_(); ws.view(torch.int64)[-(1 << 17):].zero_()
+    torch.cuda.synchronize()
+    O.conv3x3(x, wt, bi, b, h, w)
+    torch.cuda.synchronize()
+    st = ws.view(torch.int64)[-(1 << 17):].cpu().reshape(-1, 8)
+    st = st[st[:, 7] != 0]
+    n = st.shape[0]
+    t = (st[:, 1:6] - st[:, 0:1]).double()
+    real = (st[:, 7] - st[:, 6]).double() * 10.0           # ns (100 MHz)
+    clk = (st[:, 5] - st[:, 0]).double() / real             # GHz
+    span = (st[:, 7].max() - st[:, 6].min()).item() * 10.0
+    print("conv %dx%d C=%d: %d workgroups, kernel span %.1f us, in-kernel clock median %.2f GHz" %
+          (h, w, c, n, span / 1e3, clk.median().item()))
+    print("   start spread %.1f us" % ((st[:, 6].max() - st[:, 6].min()).item() / 100.0))
+    names = ("tables", "prologue issued", "first 9 steps", "loop done", "stored")
+    for i, nm in enumerate(names):
+        print("   %-16s median %8.0f cyc  (p10 %8.0f, p90 %8.0f)" % (nm, t[:, i].median().item(),
+              t[:, i].quantile(0.1).item(), t[:, i].quantile(0.9).item()))

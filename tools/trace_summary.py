@@ -40,3 +40,12 @@ print("steps %d  wall %.3f ms/step  union-busy %.3f ms/step  idle %.1f%%  sum-of
     sum(busy.values()) / union, len(win) / steps))
 for k, v in busy.most_common():
     print("  %-16s %5d launches/step  %8.3f ms/step  avg %7.1f us" % (k, cnt[k] / steps, v / steps / 1e6, v / cnt[k] / 1e3))
+# the launches that are not this library's kernels, by (short) name
+other = collections.defaultdict(lambda: [0, 0])
+for s, e, n in win:
+    if cls(n) == "torch/other":
+        m = re.search(r"(\w+Functor\w*|\w+copy_kernel\w*|CatArray\w+|gather_kernel|index\w+|Cijk\w{0,20}|\w+_kernel)", n)
+        key = (m.group(1) if m else n[:60]) + (" <Half>" if "Half" in n else "") + (" <float>" if "float" in n else "")
+        other[key][0] += 1; other[key][1] += e - s
+for k, (c, t) in sorted(other.items(), key=lambda kv: -kv[1][1]):
+    print("    other: %-60s %5.1f /step  %7.1f us/step  avg %6.1f us" % (k[:60], c / steps, t / steps / 1e3, t / c / 1e3))
