@@ -47,6 +47,7 @@ struct GemmParams {
   const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
   const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
   int no_stagger;                        // conv3s A/B switch (DD_STAGGER=0)
+  int persist;                           // dd_gemm2_kernel: the grid is smaller than the tile count (see the kernel)
   uint64_t* dbg_stamps;                  // DD_DBG_STAMP builds only
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
   void* ln_out; int64_t ld_ln_out;       // LayerNorm EMITTED by the epilogue of the 80x320 tile (second output)
@@ -719,12 +720,16 @@ void dd_gemm2_kernel(const GemmParams p) {
   const int wave_m = wave / WAVES_N;
   const int wave_n = wave % WAVES_N;
 
+  // PERSISTENT mode (p.persist: dense, no split-K, more tiles than resident workgroups): a workgroup walks the tiles
+  // lin, lin + gridDim.x, ... and the DMA ring runs AHEAD across the tile boundary — the first NSTAGE-1 stages of
+  // the next tile are issued during the last K-steps of the current one, so only the very first tile of a workgroup
+  // pays the pipeline fill (measured: 25 % of a 5-step tile's life at K = 320, tools/gemm2_stamps.py) and the
+  // epilogue's stores overlap the next tile's loads.
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tile_m = tile / p.tiles_n;
-  const int tile_n = tile % p.tiles_n;
-  const int block_m0 = tile_m * BM;
-  const int block_n0 = tile_n * BN_OUT;
+  int lin = blockIdx.x;                              // the tile being multiplied (consumer side)
+  int tile = xcd_remap(lin, ntiles);
+  int block_m0 = (tile / p.tiles_n) * BM;
+  int block_n0 = (tile % p.tiles_n) * BN_OUT;
 
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.k, kbeg + p.k_per_split);
@@ -743,6 +748,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   // a tap or the seam.  Exactly ONE DMA instruction per (operand, j) and stage: the counted vmcnt
   // waits below rely on it.
   uint32_t wv[WI];                                  // weight rows: n * K * 2 + chunk, or out of range
+  auto make_wv = [&](const int bn0) __attribute__((always_inline)) {
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
     const int R = (j * NW + wave) * 8 + lrow;
@@ -754,15 +760,17 @@ void dd_gemm2_kernel(const GemmParams p) {
       constexpr int TH = TN / 2;
       const int t = tn % TH;
       const int loc = wvi * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
-      const int col = block_n0 + loc;
+      const int col = bn0 + loc;
       n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
     } else {
       const int loc = wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
-      const int col = block_n0 + loc;
+      const int col = bn0 + loc;
       n_glob = (col < p.n) ? col : -1;
     }
     wv[j] = n_glob >= 0 ? (uint32_t)n_glob * (uint32_t)p.k * 2u + lcb : DD_OOB;
   }
+  };
+  make_wv(block_n0);
 
   uint32_t xe[XI];                                  // activation rows: offsets for the current tap / source a
   uint32_t xe2[CONV ? 1 : XI];                      // dense: offsets into a2
@@ -805,6 +813,15 @@ void dd_gemm2_kernel(const GemmParams p) {
       xe2[j] = rv ? (uint32_t)r * (uint32_t)p.lda2 * 2u + lcb : DD_OOB;
     }
   }
+  auto make_xe = [&](const int bm0) __attribute__((always_inline)) {       // dense: tables of another row tile
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int r = bm0 + (j * NW + wave) * 8 + lrow;
+      const bool rv = r < p.rows;
+      xe[j] = rv ? (uint32_t)r * (uint32_t)p.lda * 2u + lcb : DD_OOB;
+      xe2[j] = rv ? (uint32_t)r * (uint32_t)p.lda2 * 2u + lcb : DD_OOB;
+    }
+  };
   // conv: point xe[] at tap `tap` (table select by mask arithmetic: a select of array elements
   // would force the tables to scratch)
   auto set_tap = [&](int tap) __attribute__((always_inline)) {
@@ -953,13 +970,15 @@ void dd_gemm2_kernel(const GemmParams p) {
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  int sbase = 0;                       // ring slot of this tile's stage 0 (persistent: tiles follow each other in the ring)
+  bool have_next = false;              // persistent: another tile follows, its first stages are issued from this one
   auto kstep = [&](const int kt, auto par_c) __attribute__((always_inline)) {
     constexpr int par = STAG ? decltype(par_c)::value : 0;
     // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
     if (NSTAGE == 2) {
       wait_vmcnt<0>();
     } else {
-      const int ahead = min(nk - 1 - kt, NSTAGE - 2);     // scalar; stages allowed to stay in flight
+      const int ahead = have_next ? NSTAGE - 2 : min(nk - 1 - kt, NSTAGE - 2);     // scalar; stages allowed to stay in flight
       if (ahead <= 0) wait_vmcnt<0>();
       else if (ahead == 1 || NSTAGE <= 3) wait_vmcnt<(NSTAGE > 2 ? 1 : 0) * LPS>();
       else if (ahead == 2 || NSTAGE <= 4) wait_vmcnt<(NSTAGE > 3 ? 2 : 0) * LPS>();
@@ -970,11 +989,27 @@ void dd_gemm2_kernel(const GemmParams p) {
     }
     __builtin_amdgcn_s_barrier();          // everyone's share of stage kt landed; slot (kt-1) is free
     // (issuing the DMAs after the fragment reads, or between the two MFMA halves, measured the same)
-    if (kt + NSTAGE - 1 < nk) issue_next((kt + NSTAGE - 1) % NSTAGE);
+    {
+      const int a = kt + NSTAGE - 1;                 // the stage to issue now, counted from this tile's stage 0
+      const int islot = (sbase + a) % NSTAGE;
+      if (a < nk) {
+        issue_next(islot);
+      } else if (have_next) {                        // into the next tile (nk >= NSTAGE - 1: host-checked)
+        if constexpr (!CONV) {
+          if (a == nk) {                             // the issue side crosses the tile boundary: new address tables
+            const int nt = xcd_remap(lin + (int)gridDim.x, ntiles);
+            make_wv((nt % p.tiles_n) * BN_OUT);
+            make_xe((nt / p.tiles_n) * BM);
+            ik0 = kbeg;
+          }
+          issue_next(islot);
+        }
+      }
+    }
     if constexpr (STAG) {
       if (late && kt > 0) mfma_step(std::integral_constant<int, par ^ 1>{});
     }
-    const int slot = kt % NSTAGE;
+    const int slot = (sbase + kt) % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
     const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
     // all fragment reads of the K-step go out first; the MFMAs of the first half then run while the
@@ -992,6 +1027,9 @@ void dd_gemm2_kernel(const GemmParams p) {
       mfma_step(std::integral_constant<int, par>{});
     }
   };
+  const bool persist = !CONV && p.persist != 0;
+  for (;;) {
+  have_next = persist && lin + (int)gridDim.x < ntiles;
   for (int kt = 0; kt < nk; kt += 2) {
     kstep(kt, std::integral_constant<int, 0>{});
 #ifdef DD_DBG_STAMP
@@ -1015,6 +1053,17 @@ void dd_gemm2_kernel(const GemmParams p) {
   const bool ln = !CONV && p.ln_colsum;
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
                                ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr, tile);
+  if (!have_next) break;
+  lin += (int)gridDim.x;                   // next tile of this workgroup; its first stages are already in flight
+  tile = xcd_remap(lin, ntiles);
+  block_m0 = (tile / p.tiles_n) * BM;
+  block_n0 = (tile % p.tiles_n) * BN_OUT;
+  sbase = (sbase + nk) % NSTAGE;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #ifdef DD_DBG_STAMP
   DD_STAMP(5);
   if (threadIdx.x == 0 && p.dbg_stamps) {
@@ -1734,7 +1783,7 @@ inline int tile_bn(const TileCfg& t) { return t.wn * t.tn * 16; }
 
 constexpr int kNumCU = 256;
 
-struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; };
+struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; bool persist_ok; };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -1868,6 +1917,12 @@ Plan make_plan(const dd_gemm_desc* d) {
   split = ceil_div(nkt, kts);
   pl.split = split;
   pl.k_per_split = kts * BK;
+  {
+    // persistent walk with cross-tile prefetch (dd_gemm2_kernel): dense, one K range per tile, no epilogue that uses
+    // LDS or per-tile LDS state, and a K loop at least as long as the ring.  DD_PERSIST=0 is the A/B switch.
+    static const bool off = getenv("DD_PERSIST") && atoi(getenv("DD_PERSIST")) == 0;
+    pl.persist_ok = !off && !d->conv && t.stages >= 2 && split == 1 && !d->ln_colsum && !d->ln_out && nkt >= t.stages;
+  }
   return pl;
 }
 
@@ -1892,6 +1947,25 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  if constexpr (!CONV) {
+    if (pl.persist_ok) {                 // more tiles than resident workgroups: walk them with the ring running ahead
+      static std::atomic<int> resident{0};
+      int per_cu = resident.load(std::memory_order_relaxed);
+      if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * WM * WN, smem) != hipSuccess || per_cu < 1)
+          per_cu = 1;
+        resident.store(per_cu, std::memory_order_relaxed);
+      }
+      const int g = kNumCU * per_cu;
+      if ((int)grid.x > g) {
+        GemmParams q = p;
+        q.persist = 1;
+        grid.x = g;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, q);
+        return dd_check_launch();
+      }
+    }
+  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
   return dd_check_launch();
 }
@@ -2184,6 +2258,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
       p.a2_bytes = d->a2 ? (uint32_t)((((int64_t)d->rows - 1) * d->lda2 + (d->k - d->k1)) * 2) : 0u;
     }
   }
+  p.persist = 0;
   p.partial = nullptr;
   p.tile_counters = nullptr;
   p.dbg_stamps = nullptr;

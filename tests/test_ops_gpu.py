@@ -856,3 +856,40 @@ def test_ors_projection_edge_cases():
     assert (proj.project_volume(empty, [K], [inside]) == 17).all()
     cond = proj.condition_volume(empty, [K], [inside], dtype=torch.bfloat16)
     assert cond.shape == (1, 64, h, w) and (cond.float() == 1.0).all()
+
+
+# ------------------------------------------------------------------ persistent tile walk ----
+@pytest.mark.parametrize("tile", [t for t in DMA_TILES if t not in (21, 22)])
+def test_gemm_persistent_walk_dense(ops, tile):
+    """More tiles than resident workgroups and a short K loop (the QKV / to_out shapes of the 28x50 level): the
+    LDS-DMA family walks several tiles per workgroup with the ring running ahead across the tile boundary
+    (dd_gemm2_kernel, persistent mode).  Two-source A, bias, time-embedding vector, residual, ragged last row tile;
+    every tile configuration must give the SAME bits (same K order per output element) and match the fp32 reference."""
+    dtype = torch.float16
+    rows, n, k = 16800 - 37, 960, 320
+    a = rnd((rows, 192), dtype, 1)
+    a2 = rnd((rows, k - 192), dtype, 11)
+    w = rnd((n, k), dtype, 2, 0.05)
+    b = rnd((n,), dtype, 3)
+    res = rnd((rows, n), dtype, 4)
+    y = ops.gemm(a, w, b, a2=a2, res=res, tile=tile, split_k=1)
+    check(y, L.linear_ref(a, w, b, a2=a2, res=res), dtype, "persistent dense tile%d" % tile)
+    y0 = ops.gemm(a, w, b, a2=a2, res=res, tile=12, split_k=1)
+    assert torch.equal(y, y0), "tile %d and tile 12 disagree bitwise" % tile
+
+
+@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29])
+def test_gemm_persistent_walk_geglu_headmajor(ops, tile):
+    dtype = torch.bfloat16
+    rows, c = 16800, 320
+    a = rnd((rows, c), dtype, 1)
+    w = rnd((8 * c, c), dtype, 2, 0.05)
+    b = rnd((8 * c,), dtype, 3)
+    y = ops.gemm(a, w, b, epilogue=ops.DD_EPI_GEGLU, tile=tile)
+    check(y, L.linear_ref(a, w, b, geglu=True), dtype, "persistent geglu tile%d" % tile, 2.0)
+    if tile != 29:
+        w3 = rnd((3 * c, c), dtype, 5, 0.05)
+        hm = ops.gemm(a, w3, None, head_major=(40, 8, 0.5), tile=tile)        # (24 planes, rows, 40)
+        ref = L.linear_ref(a, w3, None).reshape(rows, 24, 40).permute(1, 0, 2).clone()
+        ref[:8] *= 0.5
+        check(hm, ref, dtype, "persistent head-major tile%d" % tile, 2.0)
