@@ -1204,6 +1204,8 @@ void dd_conv3s_kernel(const GemmParams p) {
   //  kernel in front of the first load; now they run under the 2-3 us the cold weights need to arrive)
   // ---- per-lane tap tables: LDS row of the pixel each tap reads (BM = the zero row), 2 x 16 bit
   uint32_t tab[TM][5];
+  // Branch-free (bit selects on 0 / ~0 masks): written with `if`s the compiler emitted 120 exec-mask regions for
+  // the 60 entries and the build took 6 200 cycles of a 69 000-cycle kernel (tools/conv3s_stamps.py).
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int r = wave_m * (TM * 16) + tm * 16 + (lane & 15);
@@ -1213,25 +1215,27 @@ void dd_conv3s_kernel(const GemmParams p) {
     const int rem = rr - g * hw;
     const int y = dd_fdiv(rem, p.inv_wout);
     const int x = rem - y * p.wout;
+    const uint32_t mrv = 0u - (uint32_t)rv;
+    const uint32_t my[3] = {mrv & (0u - (uint32_t)(y >= 1)), mrv, mrv & (0u - (uint32_t)(y + 1 < p.hout))};
+    const uint32_t mx[3] = {0u - (uint32_t)(x >= 1), ~0u, 0u - (uint32_t)(x + 1 < p.wout)};
 #pragma unroll
     for (int t2 = 0; t2 < 5; ++t2) {
       uint32_t packed = 0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int t = t2 * 2 + h;
-        // padding taps read one of the 16 zero rows BM .. BM+15, chosen so that the 16 lanes of an MFMA row
-        // block keep DISTINCT rows mod 16 — a valid tap reads row r + dy*W + dx, a padded one the zero row with
-        // the same residue — which is what keeps ds_read_b128 conflict-free under the (row >> 1) & 7 swizzle
-        // (one shared zero row cost 34-39 % of the LDS cycles in bank conflicts at the 4x7 / 7x13 levels,
+        // A valid tap reads slab row r + dy*W + dx (= g*hw + iy*W + ix).  A padding tap reads one of the 16 zero rows
+        // BM .. BM+15, the one with the residue mod 16 the real pixel would have had: the 16 lanes of an MFMA row
+        // block keep DISTINCT rows mod 16, which is what keeps ds_read_b128 conflict-free under the row & 7
+        // swizzle (one shared zero row cost 34-39 % of the LDS cycles in bank conflicts at the 4x7 / 7x13 levels,
         // where a third of all taps are padding)
-        uint32_t ra = BM + ((uint32_t)(r + (t < 9 ? (t / 3 - 1) * p.wout + (t % 3 - 1) : 0)) & 15u);
-        if (t < 9) {
-          const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-          if (rv && iy >= 0 && iy < p.hout && ix >= 0 && ix < p.wout) ra = (uint32_t)(g * hw + iy * p.wout + ix);
-        }
+        const uint32_t lin = (uint32_t)(r + (t < 9 ? (t / 3 - 1) * p.wout + (t % 3 - 1) : 0));
+        const uint32_t pad = (uint32_t)BM | (lin & 15u);            // BM is a multiple of 16
+        const uint32_t ok = t < 9 ? (my[t < 9 ? t / 3 : 0] & mx[t < 9 ? t % 3 : 0]) : 0u;
+        uint32_t ra = (lin & ok) | (pad & ~ok);
         // the entry is the fragment's LDS address in 16-byte units: row * 8 + swizzled chunk of k-step 0
         // (k-step 1 is the same address with bit 2 of the chunk flipped); AROWS * 8 + 7 < 2^16
-        ra = ra * 8u + ((uint32_t)(lane >> 4) ^ (ra & 7u));
+        ra = (ra << 3) | ((uint32_t)(lane >> 4) ^ (ra & 7u));
         packed |= ra << (16 * h);
       }
       tab[tm][t2] = packed;
