@@ -471,3 +471,28 @@ def test_multiview_block_unknown_variant_raises(gpu):
     with pytest.raises(TypeError):                           # blocks.py:89-90
         BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR,
                                        zero_module_type="relu")
+
+
+def test_foreign_checkpoint_import_forward(gpu, tmp_path):
+    """a diffusers-layout `unet/` folder written by other code (oracle weights, hand-written 0.17.1
+    config.json, safetensors) -> `from_pretrained(..., torch_dtype=fp16)` -> `.to('cuda')` -> `forward()` reproduces the
+    oracle that produced the weights (real SD-v1.5 widths, one layer per block)."""
+    from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from tests.test_host_logic import write_foreign_unet_checkpoint
+    dtype = torch.float16
+    ora, sd = write_foreign_unet_checkpoint(os.path.join(tmp_path, "unet"), "safetensors", seed=23,
+                                            block_out_channels=[320, 640, 1280, 1280], cross_attention_dim=768)
+    net = UNet2DConditionModelMultiview.from_pretrained(str(tmp_path), subfolder="unet", torch_dtype=dtype).to("cuda")
+    x = bf16_round(seeded_tensor((6, 4, 28, 50), 1))
+    ctx = bf16_round(seeded_tensor((6, 20, 768), 2))
+    t = torch.tensor([601])
+    with torch.no_grad():
+        y = net(x.cuda().to(dtype), t.cuda(), encoder_hidden_states=ctx.cuda().to(dtype)).sample
+    rec = []
+    # the checkpoint holds fp32 values and from_pretrained rounds them to fp16: the oracle runs ON THE LOADED VALUES
+    ora.load_state_dict({k: v.float().cpu() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        ref = ora(x, t, encoder_hidden_states=ctx).sample
+        with storage_emulation(ora, dtype):
+            emul = ora(x, t, encoder_hidden_states=ctx).sample
+    assert report("foreign checkpoint unet eps", y, ref, dtype, rec, emul) <= 1.0, rec
