@@ -88,6 +88,8 @@ SIGNATURES = {
                                    c_int32, c_int32, c_void_p]),
     "dd_conv3x3_small_cout": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                         c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "dd_conv3x3_thin": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, c_int32, c_int32, c_void_p]),
     "dd_cfg_ddim_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_int64, c_int32, c_void_p]),
 }

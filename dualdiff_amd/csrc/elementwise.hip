@@ -207,6 +207,114 @@ void dd_conv3x3_small_kernel(const T* x, const T* w, const T* bias, T* y,
   }
 }
 
+// ---- conv3x3 for THIN channel counts on large images (the condition embedder's first layers) ------------------------
+// map_embedder.py:79-113: 3 -> 16 -> 16 -> 32 (stride 2) -> 32 channels on 224x400 .. 112x200 images (1.07 M output
+// pixels per layer at 12 view-instances).  As an implicit GEMM these are N = 16 / 32, K = 72 .. 288 problems whose every
+// input pixel is gathered 9 times through L2 (90 us, 0.76 TB/s of algorithmic bytes for 16 -> 16).  Here a workgroup
+// owns a TH x 64 block of output pixels: the input patch (with its halo) is staged ONCE in LDS (zero-filled outside the
+// image), the whole weight matrix lives in registers as MFMA A-fragments (<= 18 x 4 VGPRs), and each wave walks 16-pixel
+// row segments: one ds_read_b128 per lane and K-step supplies 8 consecutive (tap, channel) values of its pixel.
+// HBM-bound by construction: input read once (+ halo), output written once.
+template <typename T, int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256)
+void dd_conv3x3_thin_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
+                            T* __restrict__ y, int hin, int win, int hout, int wout, int silu) {
+  using V8 = typename dd_vec<T>::v8;
+  using V4 = typename dd_vec<T>::v4;
+  constexpr int TW = 64, TH = STRIDE == 1 ? 8 : 4;           // output pixels per workgroup
+  constexpr int PW = (TW - 1) * STRIDE + 3, PH = (TH - 1) * STRIDE + 3;
+  constexpr int PIX = CIN * 2 + (CIN > 8 ? 16 : 0);           // bytes per patch pixel: +16 keeps 16 pixels' reads apart
+  constexpr int TPK = 32 / CIN;                               // taps per 32-wide K-step
+  constexpr int KSTEPS = (9 + TPK - 1) / TPK;
+  constexpr int NB = COUT / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, kc = lane >> 4;
+  const int tiles_x = (wout + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int inst = blockIdx.y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const T* xin = x + (int64_t)inst * hin * win * CIN;
+
+  // ---- stage the patch: 16-B vectors, rows of PW pixels x CIN channels ------------------------------------------------
+  constexpr int VPP = CIN / 8;                                // 16-B vectors per pixel
+  constexpr int NVEC = PH * PW * VPP;
+  for (int v = tid; v < NVEC; v += 256) {
+    const int pix = v / VPP, cv = v - pix * VPP;
+    const int py = pix / PW, pxx = pix - py * PW;
+    const int iy = iy0 + py, ix = ix0 + pxx;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (iy >= 0 && iy < hin && ix >= 0 && ix < win) val = dd_ld16(xin + ((int64_t)iy * win + ix) * CIN + cv * 8);
+    *reinterpret_cast<u32x4*>(smem + (size_t)pix * PIX + cv * 16) = val;
+  }
+  // ---- weights -> registers (A operand: row = output channel px, 8 consecutive k of chunk kc) ----------------------------
+  V8 wf[NB][KSTEPS];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int k = ks * 32 + kc * 8;                         // (tap, channel) index; >= 9 * CIN: padding taps
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (k < 9 * CIN) val = dd_ld16(w + (int64_t)(nb * 16 + px) * (9 * CIN) + k);
+      wf[nb][ks] = dd_as_v8<T>(val);
+    }
+  // this lane's patch offset per K-step, relative to its output pixel's top-left tap
+  int koff[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int k = ks * 32 + kc * 8;
+    int tap = k / CIN;
+    const int ci = k - tap * CIN;
+    if (tap > 8) tap = 0;                                     // zero weights: any resident address will do
+    koff[ks] = ((tap / 3) * PW + (tap % 3)) * PIX + ci * 2;
+  }
+  float bv[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[nb][r] = bias ? (float)bias[nb * 16 + kc * 4 + r] : 0.f;
+  __syncthreads();
+
+  constexpr int ROWS_PER_WAVE = TH / 4;
+  T* yout = y + (int64_t)inst * hout * wout * COUT;
+#pragma unroll
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int oy = oy0 + wave * ROWS_PER_WAVE + rr;
+    if (oy >= hout) continue;                                 // wave-uniform
+    const int prow = (wave * ROWS_PER_WAVE + rr) * STRIDE;
+#pragma unroll
+    for (int g = 0; g < TW / 16; ++g) {
+      const int ox = ox0 + g * 16 + px;
+      if (ox0 + g * 16 >= wout) continue;                     // wave-uniform
+      const unsigned char* base = smem + (size_t)(prow * PW + (g * 16 + px) * STRIDE) * PIX;
+      f32x4 acc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const V8 xf = dd_as_v8<T>(*reinterpret_cast<const u32x4*>(base + koff[ks]));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = dd_mfma16(wf[nb][ks], xf, acc[nb]);
+      }
+      if (ox < wout) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          V4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[nb][r] + bv[nb][r];
+            if (silu) v = dd_silu_f(v);
+            o[r] = (T)v;
+          }
+          *reinterpret_cast<V4*>(yout + ((int64_t)oy * wout + ox) * COUT + nb * 16 + kc * 4) = o;
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256)
 void dd_cfg_ddim_kernel(const T* eps, const T* x, T* x_out, T* x_dup, const float* coef,
@@ -438,6 +546,45 @@ extern "C" int dd_conv3x3_small_cout(const void* x, const void* w, const void* b
                        (const __bf16*)x, (const __bf16*)w, (const __bf16*)bias,
                        (__bf16*)y_nchw, m, h, wd, cin, cout);
   return dd_check_launch();
+}
+
+template <typename T, int CIN, int COUT, int STRIDE>
+static int launch_thin(const void* x, const void* w, const void* bias, void* y, int m, int hin, int win, int hout, int wout,
+                       int silu, hipStream_t s) {
+  constexpr int TW = 64, TH = STRIDE == 1 ? 8 : 4;
+  constexpr int PW = (TW - 1) * STRIDE + 3, PH = (TH - 1) * STRIDE + 3;
+  constexpr int PIX = CIN * 2 + (CIN > 8 ? 16 : 0);
+  constexpr size_t smem = (size_t)PH * PW * PIX;
+  static_assert(smem <= 64 * 1024, "patch fits the default dynamic LDS limit");
+  dim3 grid(((wout + TW - 1) / TW) * ((hout + TH - 1) / TH), m);
+  hipLaunchKernelGGL((dd_conv3x3_thin_kernel<T, CIN, COUT, STRIDE>), grid, dim3(256), smem, s, (const T*)x, (const T*)w,
+                     (const T*)bias, (T*)y, hin, win, hout, wout, silu);
+  return dd_check_launch();
+}
+
+template <typename T>
+static int launch_thin_t(const void* x, const void* w, const void* bias, void* y, int m, int hin, int win, int hout, int wout,
+                         int cin, int cout, int stride, int silu, hipStream_t s) {
+#define DD_THIN(CI, CO, ST) if (cin == CI && cout == CO && stride == ST) \
+    return launch_thin<T, CI, CO, ST>(x, w, bias, y, m, hin, win, hout, wout, silu, s);
+  DD_THIN(8, 16, 1) DD_THIN(16, 16, 1) DD_THIN(16, 32, 2) DD_THIN(32, 32, 1)
+  DD_THIN(8, 32, 1) DD_THIN(16, 32, 1) DD_THIN(16, 16, 2) DD_THIN(8, 16, 2) DD_THIN(32, 16, 1)
+#undef DD_THIN
+  return DD_ERR_UNSUPPORTED;
+}
+
+extern "C" int dd_conv3x3_thin(const void* x, const void* w, const void* bias, void* y, int32_t m, int32_t hin, int32_t win,
+                               int32_t cin, int32_t cout, int32_t stride, int32_t silu, int32_t dtype, dd_stream_t stream) {
+  if (!x || !w || !y || m <= 0 || hin <= 0 || win <= 0) return DD_ERR_BAD_ARG;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(x) || !dd_aligned16(w) || !dd_aligned16(y) || (reinterpret_cast<uintptr_t>(bias) & 1u)) return DD_ERR_BAD_ARG;
+  if (stride != 1 && stride != 2) return DD_ERR_UNSUPPORTED;
+  if (m > 65535) return DD_ERR_UNSUPPORTED;
+  const int hout = (hin - 1) / stride + 1, wout = (win - 1) / stride + 1;      // kernel 3, pad 1
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
+  if (dtype == DD_F16) return launch_thin_t<_Float16>(x, w, bias, y, m, hin, win, hout, wout, cin, cout, stride, silu, s);
+  return launch_thin_t<__bf16>(x, w, bias, y, m, hin, win, hout, wout, cin, cout, stride, silu, s);
 }
 
 extern "C" int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, void* x_dup,

@@ -465,6 +465,14 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     return hm_out if hm_out is not None else out
 
 
+_THIN_CONV = _os.environ.get("DD_THIN_CONV", "1") != "0"       # A/B switch of dd_conv3x3_thin
+
+
+def thin_conv_ok(cin, cout, stride, m):
+    return _THIN_CONV and (cin, cout, stride) in ((8, 16, 1), (16, 16, 1), (16, 32, 2), (32, 32, 1), (8, 32, 1), (16, 32, 1),
+                                                  (16, 16, 2), (8, 16, 2), (32, 16, 1)) and m <= 65535
+
+
 def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res=None,
             alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0):
     """3x3 / pad 1 convolution as an implicit GEMM on an NHWC batch.
@@ -487,6 +495,18 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     rows = m * hout * wout
     if out is None:
         out = torch.empty((rows, cout), dtype=x.dtype, device=x.device)
+    if thin_conv_ok(cin, cout, stride, m) and up_size is None and rowvec is None and res is None and alpha == 1.0 \
+            and not accumulate and epilogue in (DD_EPI_NONE, DD_EPI_SILU) and tile == 0 and split_k == 0 \
+            and out.is_contiguous():
+        # thin channel counts on a large image (the condition embedder's first layers): patch-in-LDS direct conv
+        e0 = _TIMER.start() if _TIMER is not None else None
+        rc = lib.dd_conv3x3_thin(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), m, hin, win, cin, cout, stride,
+                                 int(epilogue == DD_EPI_SILU), _dt(x), _stream())
+        _native.check(rc, "conv3x3_thin")
+        if _TIMER is not None:
+            _TIMER.stop(e0, "dd_conv3x3_thin_kernel" + (" conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else ""),
+                        2.0 * rows * cout * 9 * cin, 2.0 * (x.numel() + w.numel() + rows * cout))
+        return out
     d = GemmDesc()
     d.a = x.data_ptr(); d.lda = cin; d.k1 = 9 * cin
     d.rows, d.n, d.k = rows, cout, 9 * cin

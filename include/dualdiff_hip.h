@@ -299,6 +299,14 @@ int dd_conv3x3_small_cout(const void* x, const void* w, const void* bias, void* 
                           int32_t m, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                           int32_t dtype, dd_stream_t stream);
 
+/* conv3x3 / pad 1 / stride 1 or 2 for THIN channel counts on large NHWC images — the first layers of
+ * ControlNetConditioningEmbedding (networks/map_embedder.py:79-113: 3 -> 16 -> 16 -> 32 -> 32 channels on 224x400 ..
+ * 112x200).  x (m, hin, win, cin), w [cout][9*cin] (k = tap * cin + channel), bias [cout] or NULL,
+ * y (m, hout, wout, cout) with hout = (hin - 1) / stride + 1; optional SiLU.  cin in {8, 16, 32} (3 input channels are
+ * zero-padded to 8 by the caller), cout in {16, 32}; other combinations: DD_ERR_UNSUPPORTED. */
+int dd_conv3x3_thin(const void* x, const void* w, const void* bias, void* y, int32_t m, int32_t hin, int32_t win,
+                    int32_t cin, int32_t cout, int32_t stride, int32_t silu, int32_t dtype, dd_stream_t stream);
+
 /* Classifier-free guidance + DDIM (eta = 0) update, fused:
  *   eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);
  *   x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps

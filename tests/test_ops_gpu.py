@@ -893,3 +893,30 @@ def test_gemm_persistent_walk_geglu_headmajor(ops, tile):
         ref = L.linear_ref(a, w3, None).reshape(rows, 24, 40).permute(1, 0, 2).clone()
         ref[:8] *= 0.5
         check(hm, ref, dtype, "persistent head-major tile%d" % tile, 2.0)
+
+
+# ------------------------------------------------------------------ thin conv (condition embedder) ----
+THIN_CASES = [(8, 16, 1), (16, 16, 1), (16, 32, 2), (32, 32, 1), (8, 32, 1), (16, 32, 1), (16, 16, 2), (8, 16, 2),
+              (32, 16, 1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,stride", THIN_CASES)
+@pytest.mark.parametrize("m,h,w_", [(3, 37, 53), (2, 8, 64), (1, 5, 200), (2, 56, 100)])
+def test_conv3x3_thin_channels(ops, dtype, cin, cout, stride, m, h, w_):
+    """dd_conv3x3_thin (first layers of ControlNetConditioningEmbedding, map_embedder.py:79-113): odd image sizes
+    (partial tiles in both directions, borders inside a tile), both strides, bias + SiLU, against the fp32 reference."""
+    assert ops.thin_conv_ok(cin, cout, stride, m)
+    real_cin = 3 if cin == 8 else cin                          # 3 condition channels arrive zero-padded to 8
+    x = rnd((m * h * w_, cin), dtype, 1)
+    if real_cin != cin:
+        x[:, real_cin:] = 0
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * real_cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    for silu in (False, True):
+        y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, stride=stride,
+                        epilogue=ops.DD_EPI_SILU if silu else ops.DD_EPI_NONE)
+        ref = L.conv3x3_ref(x, w, b, m, h, w_, stride=stride)
+        if silu:
+            ref = torch.nn.functional.silu(ref)
+        check(y, ref, dtype, "thin conv %d->%d s%d %dx%d silu=%d" % (cin, cout, stride, h, w_, silu))
