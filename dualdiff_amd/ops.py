@@ -198,15 +198,16 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / iters
-        total = 0.0
+        samples = []
         for _ in range(iters):
             _flush_and_warm(device, warm)
             e0.record()
             lib.dd_gemm(ctypes.byref(d), stream)
             e1.record()
             e1.synchronize()
-            total += e0.elapsed_time(e1)
-        return total / iters
+            samples.append(e0.elapsed_time(e1))
+        samples.sort()
+        return samples[len(samples) // 2]         # median: one slow launch (clock ramp, a neighbour's burst) must not decide
 
     cands = []
     excl = {int(t) for t in _os.environ.get("DD_TUNE_EXCLUDE", "").split(",") if t.strip()}   # A/B experiments
@@ -221,8 +222,8 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
                 cands.append((t, tile, split))
     # the coarse pass is noisy: re-time the front-runners with more launches
     cands.sort()
-    for t, tile, split in cands[:6]:
-        t2 = timed(tile, split, 6 if _COLD else 12)
+    for t, tile, split in cands[:8]:
+        t2 = timed(tile, split, 15 if _COLD else 12)
         if t2 is not None and t2 < best_t:
             best, best_t = (tile, split), t2
     (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
