@@ -1766,6 +1766,11 @@ constexpr TileCfg kTiles[] = {
     // 80 WHOLE rows of a 320-wide output per workgroup (1 x 10 waves): the only tile whose epilogue can emit
     // LayerNorm(out) as a second tensor (dd_gemm_desc.ln_out); 16800 rows -> 210 workgroups, one generation
     {40, 1, 10, 5, 2, 2, "80x320/dma2"},
+    // 192 rows: 1092 rows -> 6 row tiles (180 workgroups at N = 3840 where 256x128 has 150): the per-CU staging rate,
+    // not the tile's arithmetic intensity, bounds a launch that leaves CUs without a workgroup (1092x3840x1280:
+    // 26.5 -> 23.2 us cold, 1092x1280x6400: 41.4 -> 37.6)
+    {44, 4, 2, 3, 4, 3, "192x128/dma3"},
+    {46, 4, 2, 3, 4, 2, "192x128/dma2"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -2064,6 +2069,8 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
     case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
     case 40: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 1, 10, 5, 2, 2, false, false>(p, pl, s); break;
+    case 44: return launch_cfg2<T, 4, 2, 3, 4, 3, CONV, GEGLU>(p, pl, s);
+    case 46: return launch_cfg2<T, 4, 2, 3, 4, 2, CONV, GEGLU>(p, pl, s);
     case 29: if constexpr (GEGLU) return launch_cfg2<T, 2, 5, 5, 4, 2, false, true>(p, pl, s); break;   // 168 VGPRs: only the GEGLU form fits without spills
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);

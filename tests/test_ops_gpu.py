@@ -49,8 +49,8 @@ def test_gemm_identity_asymmetric(ops):
     check(y, w.float().cpu().t(), torch.float16, "gemm A=I")
 
 
-ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28]
-DMA_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28]     # 29 is GEGLU-only
+ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46]
+DMA_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46]     # 29 is GEGLU-only
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -415,7 +415,7 @@ def test_gemm_layernorm_fold_rejects(ops):
         ops.gemm(x, w, None, ln=(z, z, 1e-5), tile=1)         # register-staged family has no fold
 
 
-@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29])
+@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29, 44, 46])
 def test_gemm_geglu_dma_tiles(ops, tile):
     dtype = torch.bfloat16
     rows, c = 700, 640
@@ -878,7 +878,7 @@ def test_gemm_persistent_walk_dense(ops, tile):
     assert torch.equal(y, y0), "tile %d and tile 12 disagree bitwise" % tile
 
 
-@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29])
+@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29, 44, 46])
 def test_gemm_persistent_walk_geglu_headmajor(ops, tile):
     dtype = torch.bfloat16
     rows, c = 16800, 320
