@@ -17,6 +17,13 @@
 //    that read the neighbours' K/V in place and sum the normalised outputs.
 #include "dd_common.h"
 
+// DD_DBG_NOEXP (diagnostic build only, tools/build_dbg_libs.sh): the exponentials of the softmax become moves
+#ifdef DD_DBG_NOEXP
+#define DD_EXP2(x) (x)
+#else
+#define DD_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+
 namespace {
 
 constexpr float RESCALE_THR = 5.0f;    // log2 units: probabilities stay <= 32
@@ -209,7 +216,7 @@ void dd_attn_kernel(const AttnParams p) {
           float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
           const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
-          const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+          const float alpha = DD_EXP2(m_run[j] - m_new);
           m_run[j] = m_new;
           if (!ONES) l_run[j] *= alpha;
 #pragma unroll
@@ -223,7 +230,7 @@ void dd_attn_kernel(const AttnParams p) {
         V8 pv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], p.scale_log2, -m_use));
+          const float pe = DD_EXP2(fmaf(s[e], p.scale_log2, -m_use));
           if (!ONES) ls += pe;
           pv[e] = (T)pe;
         }
@@ -498,7 +505,7 @@ void dd_attn5_kernel(const AttnParams p) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (!first) mx = fmaxf(mx, 0.f);              // the running max never decreases
             mx = fmaxf(mx, -1e30f);                        // a fully masked row keeps a finite max
-            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-mx);
+            const float alpha = first ? 1.0f : DD_EXP2(-mx);
             m_run[j] += mx;
             cinit[j] = f32x4{-m_run[j], -m_run[j], -m_run[j], -m_run[j]};
 #pragma unroll
@@ -513,7 +520,7 @@ void dd_attn5_kernel(const AttnParams p) {
           float ls = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float pe = __builtin_amdgcn_exp2f(s[e]);
+            const float pe = DD_EXP2(s[e]);
             if (!ONES) ls += pe;
             pv[e] = (T)pe;
           }
@@ -528,7 +535,7 @@ void dd_attn5_kernel(const AttnParams p) {
             float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+            const float alpha = DD_EXP2(m_run[j] - m_new);
             m_run[j] = m_new;
             if (!ONES) l_run[j] *= alpha;
 #pragma unroll
@@ -541,7 +548,7 @@ void dd_attn5_kernel(const AttnParams p) {
           float ls = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], p.scale_log2, -m_use));
+            const float pe = DD_EXP2(fmaf(s[e], p.scale_log2, -m_use));
             if (!ONES) ls += pe;
             pv[e] = (T)pe;
           }
