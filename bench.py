@@ -37,6 +37,10 @@ H, W, NCAM, NBOX, LTXT = 28, 50, 6, 20, 77
 GF_UNET, GF_CNET = 324.1, 84.7
 PEAK_HBM_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
+# Not a contract roof: the L2 -> LDS staging rate the tiled kernels of this build saturate, MEASURED on MI355X with the
+# matrix instructions compiled out (tools/stage_rate.py: 12.4-14.5 TB/s whatever the tile).  Reported per
+# class as `l2_stage` next to the contract's hbm / mfma fraction.
+MEASURED_L2_STAGE_GBPS = 14000.0
 
 
 def build_models(dtype, device, dual=True, frames=1, fp8=False, lora_rank=0):
@@ -267,7 +271,11 @@ def _roofline_row(name, d, table):
             "frac": round(gbps / PEAK_HBM_GBPS if hbm else tflops / PEAK_MFMA_TFLOPS, 4),
             "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
             "algorithmic_flops_per_launch": d["flops"] / d["count"],
-            "traffic": _pmc_traffic(name, table)}
+            "traffic": _pmc_traffic(name, table),
+            "l2_stage": (None if not d.get("staged") else
+                         {"staged_bytes_per_launch": d["staged"] / d["count"],
+                          "rate_GBps": round(d["staged"] / d["count"] / avg_s / 1e9, 1),
+                          "frac_of_measured_peak": round(d["staged"] / d["count"] / avg_s / 1e9 / MEASURED_L2_STAGE_GBPS, 4)})}
 
 
 def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline):
@@ -337,15 +345,29 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
 
         roofline = None
         if rank == 0 and want_roofline:
-            timer = O.KernelTimer()
-            timer.calibrate()                 # empty-bracket event overhead, subtracted per launch
-            O.set_timer(timer)
             par = den.parallel_branches
             den.parallel_branches = False     # one stream: event pairs must not see co-running branches
-            den._step_body()                  # instrumented eager step: HIP events around each launch
+            # Three instrumented eager steps, the one with the smallest total is kept: an event pair brackets device time
+            # only while the GPU is BEHIND the host, so ~50 ms of queued fills go first (the ~2700 launches and event
+            # records of the step are then enqueued while the GPU is still busy) — and even so a pass can catch the host
+            # in a slow moment, which inflates the short kernels (the 128x64 dense class read 22-24 us per launch in such
+            # passes against 15.3 us in clean ones and 15.8 us in rocprofv3's trace of the same build).
+            backlog = torch.empty(256 << 20, dtype=torch.uint8, device=device)
+            best = None
+            for _ in range(3):
+                timer = O.KernelTimer()
+                timer.calibrate()             # empty-bracket event overhead, subtracted per launch
+                for _ in range(600):
+                    backlog.zero_()
+                O.set_timer(timer)
+                den._step_body()              # instrumented eager step: HIP events around each launch
+                O.set_timer(None)
+                cand = timer.summary()
+                tot = sum(v["ms"] for v in cand.values())
+                if best is None or tot < best[0]:
+                    best = (tot, cand, timer)
             den.parallel_branches = par
-            O.set_timer(None)
-            summ = timer.summary()
+            summ, timer = best[1], best[2]
             table, table_name = _pmc_table()
             rows = sorted((_roofline_row(k, v, table) for k, v in summ.items()), key=lambda r: -r["ms_per_step"])
             # the dominant kernel = the MFMA/HBM-classified symbol with the largest total time

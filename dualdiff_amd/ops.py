@@ -53,20 +53,23 @@ class KernelTimer:
         e.record(torch.cuda.current_stream())
         return e
 
-    def stop(self, e0, name, flops, nbytes):
+    def stop(self, e0, name, flops, nbytes, staged=0.0):
+        """staged: bytes the launch moves from L2 into LDS (tiled GEMM / conv families: every tile re-stages its operand
+        slabs) — the quantity that actually bounds those kernels, reported beside the contract's roofs."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(torch.cuda.current_stream())
-        self.records.append((name, flops, nbytes, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1, staged))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, nbytes, e0, e1 in self.records:
-            d = out.setdefault(name, {"count": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, flops, nbytes, e0, e1, staged in self.records:
+            d = out.setdefault(name, {"count": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "staged": 0.0})
             d["count"] += 1
             d["ms"] += max(e0.elapsed_time(e1) - self.overhead_ms, 0.0)
             d["flops"] += flops
             d["bytes"] += nbytes
+            d["staged"] += staged
         return out
 
 
@@ -298,21 +301,43 @@ def _kname(lib, d):
     return name, int(rest.split(" ")[0])
 
 
+def _staged_bytes(lib, d):
+    """L2 -> LDS bytes of one dd_gemm launch, from its plan (`grid=MxN tile=BMxBN...`): every tile stages a
+    (BM + BN) x 64-element slab pair per K-step; the direct small-image conv stages its (BM + 64)-row activation slab
+    once per 64-channel chunk and a BN x 64 weight slab per (chunk, tap)."""
+    import re
+    full = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
+    m = re.search(r"grid=(\d+)x(\d+) tile=(.*)$", full)
+    if m is None:
+        return 0.0
+    tiles = int(m.group(1)) * int(m.group(2))
+    t = re.search(r"(\d+)x(\d+)", m.group(3))
+    if t is None or "rowpanel" in m.group(3):
+        return 0.0
+    bm, bn = int(t.group(1)), int(t.group(2))
+    if "conv3s" in m.group(3):
+        chunks = d.cin // 64
+        return float(tiles) * chunks * ((bm + 64) * 128.0 + 9 * bn * 128.0)
+    ksteps = (d.k + 63) // 64
+    return float(tiles) * ksteps * (bm + bn) * 128.0
+
+
 def _timed_gemm(lib, d, what, suffix, flops, nbytes, rows, n):
     """dd_gemm under the KernelTimer: a split-K GEMM's two launches are bracketed SEPARATELY (dd_gemm_desc.phase)
     and booked under their own kernel symbols, so that every class of the roofline table is one kernel symbol
     whose average duration can be checked against rocprofv3's."""
     name, split = _kname(lib, d)
+    staged = _staged_bytes(lib, d)
     if split <= 1:
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
-        _TIMER.stop(e0, name + suffix, flops, nbytes)
+        _TIMER.stop(e0, name + suffix, flops, nbytes, staged)
         return
     slab = 4.0 * split * rows * n
     d.phase = 1
     e0 = _TIMER.start()
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
-    _TIMER.stop(e0, name + suffix, flops, nbytes + slab)             # operands once + the fp32 slabs written
+    _TIMER.stop(e0, name + suffix, flops, nbytes + slab, staged)     # operands once + the fp32 slabs written
     d.phase = 2
     e0 = _TIMER.start()
     _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
