@@ -38,6 +38,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
   int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
+  int band_rows, bands; float inv_bands; // ... its BAND form: output pixels per band, bands per instance
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
   int* tile_counters;                    // split-K: per-tile arrival counters (in-kernel ordered reduction) or NULL
   int out_f32;                           // store fp32 instead of T
@@ -1085,7 +1086,11 @@ void dd_gemm2_kernel(const GemmParams p) {
 // Staged bytes drop ~5x; the weight matrix is streamed once per row tile through a 3-slot ring.
 // Requirements (host-checked): stride 1, no resize, Cin % 64 == 0.  Split-K is over channel chunks.
 // =============================================================================================
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW, int GRP = 1>
+// BAND = true: images LARGER than the tile (the 28x50 level).  A workgroup owns a band of p.band_rows consecutive output
+// pixels (whole image rows) of one instance; its slab holds those pixels plus a halo of W + 1 pixels on either side, so
+// the activation is still staged once per 64-channel chunk (the implicit-GEMM kernels stage it once per tap).  LDS rows
+// 0..15 are the zero rows, slab pixel s sits in row 16 + s; halo pixels outside the image are out-of-range DMAs = zeros.
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW, int GRP = 1, bool BAND = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 void dd_conv3s_kernel(const GemmParams p) {
   // GRP = 3: the weight ring is two GROUPS of three taps; a workgroup synchronises (DMA wait + barrier)
@@ -1096,12 +1101,12 @@ void dd_conv3s_kernel(const GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 16;
   constexpr int BN = WAVES_N * TN * 16;
-  constexpr int AROWS = BM + 64;               // rows >= BM are never valid pixels -> always zeros
-  constexpr int XA = AROWS / 8 / NW;           // activation DMA pieces per wave per chunk
+  constexpr int AROWS = BAND ? BM + 88 : BM + 64;   // rows >= BM are never valid pixels -> always zeros (BAND: see above)
+  constexpr int XA = (AROWS / 8 + NW - 1) / NW;     // activation DMA pieces per wave per chunk
   constexpr int WI = BN / 8 / NW;              // weight DMA pieces per wave per (chunk, tap) step
   // NSW weight ring slots: the weights are cold (HBM, 2-3 us) while a (chunk, tap) step lasts
   // ~0.3 us, so the ring is as deep as LDS allows
-  static_assert(AROWS % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
+  static_assert((BAND ? AROWS % 8 == 0 : AROWS % (8 * NW) == 0) && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
   static_assert(TN % 2 == 0, "TN");
   static_assert(NSW >= 3 && NSW <= 10 && (NSW - 2) * WI + XA <= 63, "ring depth / vmcnt");
 
@@ -1127,10 +1132,24 @@ void dd_conv3s_kernel(const GemmParams p) {
   const int tile_m = p.upsample ? tile / p.tiles_n : tile % p.tiles_m;      //  A/B switch DD_CONV3S_ROWMAJOR=1)
   const int hw = p.hout * p.wout;
   const int m_inst = dd_fdiv(p.rows, p.inv_hw);
-  const int g0 = tile_m * p.g_per_tile;
-  const int ng = min(p.g_per_tile, m_inst - g0);
-  const int vrows = ng * hw;                            // valid rows of this tile
-  const int row0 = g0 * hw;                             // first global output row
+  int g0_, ng_, vrows_, row0_, band0_ = 0;
+  if constexpr (BAND) {
+    g0_ = dd_fdiv(tile_m, p.inv_bands);                 // instance
+    band0_ = (tile_m - g0_ * p.bands) * p.band_rows;    // first pixel of the band inside the instance
+    ng_ = 1;
+    vrows_ = min(p.band_rows, hw - band0_);
+    row0_ = g0_ * hw + band0_;
+  } else {
+    g0_ = tile_m * p.g_per_tile;
+    ng_ = min(p.g_per_tile, m_inst - g0_);
+    vrows_ = ng_ * hw;
+    row0_ = g0_ * hw;
+  }
+  const int g0 = g0_, ng = ng_;
+  const int vrows = vrows_;                             // valid rows of this tile
+  const int row0 = row0_;                               // first global output row
+  const int band0 = band0_;
+  (void)ng; (void)g0;
   const int block_n0 = tile_n * BN;
 
   const bool stagger_off = p.no_stagger != 0;
@@ -1151,10 +1170,23 @@ void dd_conv3s_kernel(const GemmParams p) {
   const uint32_t lcb_a = (uint32_t)((lane & 7) ^ (lane >> 3)) * 16u;
   // ---- DMA tables -----------------------------------------------------------------------
   uint32_t av[XA];                                      // activation rows of the tile (raw pixels)
+  int adst[XA];                                         // BAND: LDS row of the piece (surplus pieces rewrite the zero rows)
 #pragma unroll
   for (int j = 0; j < XA; ++j) {
-    const int r = (j * NW + wave) * 8 + lrow;
-    av[j] = r < vrows ? (uint32_t)(row0 + r) * (uint32_t)p.cin * 2u + lcb_a : DD_OOB;
+    if constexpr (BAND) {
+      const int pc = j * NW + wave;                     // 8-row piece of the slab buffer
+      const bool real = pc < AROWS / 8;
+      const int L = (real ? pc : 0) * 8 + lrow;         // LDS row
+      const int sidx = L - 16;                          // slab pixel index
+      const int pix = band0 - (p.wout + 1) + sidx;      // pixel inside the instance
+      const bool ok = real && sidx >= 0 && sidx < vrows + 2 * (p.wout + 1) && pix >= 0 && pix < hw;
+      av[j] = ok ? (uint32_t)(g0 * hw + pix) * (uint32_t)p.cin * 2u + lcb_a : DD_OOB;
+      adst[j] = (real ? pc : 0) * 8;
+    } else {
+      const int r = (j * NW + wave) * 8 + lrow;
+      av[j] = r < vrows ? (uint32_t)(row0 + r) * (uint32_t)p.cin * 2u + lcb_a : DD_OOB;
+      adst[j] = (j * NW + wave) * 8;
+    }
   }
   uint32_t wv[WI];                                      // weight rows, permuted like dd_gemm2_kernel
 #pragma unroll
@@ -1173,7 +1205,7 @@ void dd_conv3s_kernel(const GemmParams p) {
     T* dst = abuf + (c & 1) * AROWS * BK;
     const uint32_t so = (uint32_t)((c_beg + c) * BK) * 2u;
 #pragma unroll
-    for (int j = 0; j < XA; ++j) bdma16(rs_a, av[j], so, dst + (j * NW + wave) * 8 * BK);
+    for (int j = 0; j < XA; ++j) bdma16(rs_a, av[j], so, dst + adst[j] * BK);
   };
   auto issue_w = [&](int c, int t, int slot) __attribute__((always_inline)) {
     T* dst = wring + slot * BN * BK;
@@ -1211,8 +1243,8 @@ void dd_conv3s_kernel(const GemmParams p) {
     const int r = wave_m * (TM * 16) + tm * 16 + (lane & 15);
     const bool rv = r < vrows;
     const int rr = rv ? r : 0;
-    const int g = dd_fdiv(rr, p.inv_hw);
-    const int rem = rr - g * hw;
+    const int g = BAND ? 0 : dd_fdiv(rr, p.inv_hw);
+    const int rem = BAND ? band0 + rr : rr - g * hw;    // pixel inside its instance
     const int y = dd_fdiv(rem, p.inv_wout);
     const int x = rem - y * p.wout;
     const uint32_t mrv = 0u - (uint32_t)rv;
@@ -1229,8 +1261,9 @@ void dd_conv3s_kernel(const GemmParams p) {
         // block keep DISTINCT rows mod 16, which is what keeps ds_read_b128 conflict-free under the row & 7
         // swizzle (one shared zero row cost 34-39 % of the LDS cycles in bank conflicts at the 4x7 / 7x13 levels,
         // where a third of all taps are padding)
-        const uint32_t lin = (uint32_t)(r + (t < 9 ? (t / 3 - 1) * p.wout + (t % 3 - 1) : 0));
-        const uint32_t pad = (uint32_t)BM | (lin & 15u);            // BM is a multiple of 16
+        // BAND: slab pixel s sits in LDS row 16 + s and output row r is slab pixel r + W + 1; zero rows are 0..15
+        const uint32_t lin = (uint32_t)(r + (BAND ? 16 + p.wout + 1 : 0) + (t < 9 ? (t / 3 - 1) * p.wout + (t % 3 - 1) : 0));
+        const uint32_t pad = (BAND ? 0u : (uint32_t)BM) | (lin & 15u);   // BM is a multiple of 16
         const uint32_t ok = t < 9 ? (my[t < 9 ? t / 3 : 0] & mx[t < 9 ? t % 3 : 0]) : 0u;
         uint32_t ra = (lin & ok) | (pad & ~ok);
         // the entry is the fragment's LDS address in 16-byte units: row * 8 + swizzled chunk of k-step 0
@@ -1774,6 +1807,7 @@ constexpr TileCfg kTiles[] = {
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
+    {39, 4, 2, 6, 2, -3, "conv3s band 384x64"},   // stages == -3: BAND form (images larger than the tile: 28x50 level)
     {33, 2, 2, 6, 2, -1, "conv3s 192x64/w8"},
     {34, 2, 2, 6, 2, -1, "conv3s 192x64/w4"},
     {35, 2, 2, 4, 2, -1, "conv3s 128x64/w3"},     // 72 KB of LDS: two workgroups per CU
@@ -1792,7 +1826,7 @@ inline int tile_bn(const TileCfg& t) { return t.wn * t.tn * 16; }
 
 constexpr int kNumCU = 256;
 
-struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; bool persist_ok; };
+struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; bool persist_ok; int band_rows, bands; };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -1871,6 +1905,31 @@ Plan make_plan(const dd_gemm_desc* d) {
     pl.tiles_n = q;
     pl.split = 1;
     pl.k_per_split = ppg;                            // panels per row group
+    return pl;
+  }
+  if (kTiles[ti].stages == -3) {                     // direct conv on row BANDS with a halo (images larger than the tile)
+    const TileCfg& t = kTiles[ti];
+    const int hw = d->hout * d->wout, W = d->wout;
+    const int arows = tile_bm(t) + 88;               // = the kernel's AROWS
+    const int R = W > 0 ? std::min(tile_bm(t), arows - 16 - 2 * (W + 1)) / W : 0;      // whole image rows per band
+    const bool ok = d->conv && !geglu && d->stride == 1 && d->hv == d->hin && d->wv == d->win &&
+                    d->hout == d->hin && d->wout == d->win && (d->cin % BK) == 0 && hw > tile_bm(t) && R >= 1 &&
+                    d->rows % hw == 0 && dma_ok(d);
+    if (!ok) { pl.unsupported = true; return pl; }
+    const int m_inst = d->rows / hw;
+    const int nchunks = d->cin / BK;
+    int split = d->split_k > 0 ? d->split_k : 1;
+    if (split > nchunks) split = nchunks;
+    const int cps = ceil_div(nchunks, split);
+    pl.tile_idx = ti;
+    pl.band_rows = R * W;
+    pl.bands = ceil_div(d->hout, R);
+    pl.g_per_tile = 1;
+    pl.tiles_m = m_inst * pl.bands;
+    pl.tiles_n = ceil_div(d->n, tile_bn(t));
+    pl.chunks_per_split = cps;
+    pl.split = ceil_div(nchunks, cps);
+    pl.k_per_split = cps * BK;
     return pl;
   }
   if (kTiles[ti].stages < 0) {                       // direct small-image conv
@@ -1979,12 +2038,12 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NSW, int GRP = 1>
+template <typename T, int WM, int WN, int TM, int TN, int NSW, int GRP = 1, bool BAND = false>
 int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr size_t smem = (size_t)(2 * (BM + 64) + NSW * BN) * BK * sizeof(T);
-  static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = dd_conv3s_kernel<T, WM, WN, TM, TN, NSW, GRP>;
+  constexpr size_t smem = (size_t)(2 * (BM + (BAND ? 88 : 64)) + NSW * BN) * BK * sizeof(T);
+  static_assert(smem <= 160 * 1024 - 64, "LDS");
+  auto kern = dd_conv3s_kernel<T, WM, WN, TM, TN, NSW, GRP, BAND>;
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
@@ -2044,6 +2103,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
   }
   switch (kTiles[pl.tile_idx].id) {
     case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
+    case 39: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5, 1, true>(p, pl, s); break;
     case 33: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 8>(p, pl, s); break;
     case 34: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 4>(p, pl, s); break;
     case 35: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 3>(p, pl, s); break;
@@ -2203,8 +2263,11 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
     return g_kname;
   }
   if (t.stages < 0) {
-    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d> split=%d grid=%dx%d tile=%s",
-             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.id == 31 ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4))), t.id >= 37 ? 3 : 1, pl.split, pl.tiles_m, pl.tiles_n, t.name);
+    const bool band = t.stages == -3;
+    const int nsw = (t.id == 31 || band) ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4)));
+    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, nsw, (t.id >= 37 && !band) ? 3 : 1,
+             band ? "true" : "false", pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
@@ -2255,6 +2318,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.scale_w = d->conv ? (float)d->win / (float)d->wv : 1.f;
   p.k_per_split = pl.k_per_split;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.band_rows = pl.band_rows; p.bands = pl.bands; p.inv_bands = pl.bands > 0 ? 1.0f / (float)pl.bands : 1.0f;
   p.inv_hw = d->conv ? 1.0f / (float)(d->hout * d->wout) : 1.0f;
   p.inv_wout = d->conv ? 1.0f / (float)d->wout : 1.0f;
   p.inv_rpi = 1.0f / (float)p.rows_per_inst;

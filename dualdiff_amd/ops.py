@@ -317,7 +317,7 @@ def _staged_bytes(lib, d):
     bm, bn = int(t.group(1)), int(t.group(2))
     if "conv3s" in m.group(3):
         chunks = d.cin // 64
-        return float(tiles) * chunks * ((bm + 64) * 128.0 + 9 * bn * 128.0)
+        return float(tiles) * chunks * ((bm + (88 if "band" in m.group(3) else 64)) * 128.0 + 9 * bn * 128.0)
     ksteps = (d.k + 63) // 64
     return float(tiles) * ksteps * (bm + bn) * 128.0
 

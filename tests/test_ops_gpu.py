@@ -920,3 +920,30 @@ def test_conv3x3_thin_channels(ops, dtype, cin, cout, stride, m, h, w_):
         if silu:
             ref = torch.nn.functional.silu(ref)
         check(y, ref, dtype, "thin conv %d->%d s%d %dx%d silu=%d" % (cin, cout, stride, h, w_, silu))
+
+
+# ------------------------------------------------------------------ direct conv on row bands (28x50 level) ----
+@pytest.mark.parametrize("case", [(12, 28, 50, 320, 320), (3, 28, 50, 640, 320), (2, 30, 41, 64, 72), (1, 20, 20, 128, 64),
+                                  (2, 70, 6, 64, 64), (5, 28, 50, 960, 320)], ids=lambda c: str(c))
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_band_direct(ops, case, dtype):
+    """BAND form of dd_conv3s_kernel (tile 39): images larger than the 384-row tile are cut into bands of whole image rows
+    with a W + 1 pixel halo on either side; first / last band (image border inside the halo), a ragged last band, widths
+    that leave 1..8 image rows per band, ResnetBlock2D epilogue, split-K over channel chunks."""
+    m, h, w_, cin, cout = case
+    x = rnd((m * h * w_, cin), dtype, 1)
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    b = rnd((cout,), dtype, 3)
+    temb = rnd((m, cout), dtype, 4)
+    res = rnd((m * h * w_, cout), dtype, 5)
+    ref = L.conv3x3_ref(x, w, b, m, h, w_) + temb.float().cpu().repeat_interleave(h * w_, 0) + res.float().cpu()
+    for split in (1, 2, 5):
+        if split > cin // 64:
+            continue
+        y = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, rowvec=temb, res=res, tile=39, split_k=split)
+        check(y, ref, dtype, "conv3s band split%d %s" % (split, case))
+    # same bits as the implicit-GEMM family's 160x160 tile?  No: different K order per output (tap-major vs chunk-major);
+    # but two band launches agree with each other bit for bit
+    y1 = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, tile=39, split_k=1)
+    y2 = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, tile=39, split_k=1)
+    assert torch.equal(y1, y2)
