@@ -420,12 +420,18 @@ void dd_attn5_kernel(const AttnParams p) {
   u32x4 kreg[PER], vreg[PER];
   auto load_kv = [&](int tile0) {
     const uint32_t ko = (uint32_t)tile0 * k_row_bytes, vo = (uint32_t)tile0 * v_row_bytes;
+#ifdef DD_DBG_NOSTAGE      // diagnostic build: no K / V staging at all (the tiles hold garbage)
+    (void)ko; (void)vo; return;
+#endif
 #pragma unroll
     for (int i = 0; i < PER; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, gk[i] + ko, 0, 0);
 #pragma unroll
     for (int i = 0; i < PER; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, gv[i] + vo, 0, 0);
   };
   auto store_kv = [&](T* tile) {
+#ifdef DD_DBG_NOSTAGE
+    (void)tile; return;
+#endif
 #pragma unroll
     for (int i = 0; i < PER; ++i)
       if (i < PER - 1 || last_slot) {

@@ -15,13 +15,13 @@ for v in nomfma nodma; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libdd_$v.so /tmp/gemm_$v.o $L/obj/norm.o $L/obj/attention.o $L/obj/elementwise.o
 done
 # attention: matrix instructions removed / exponentials replaced by moves (tools/attn_sides.py)
-for V in NOMFMA NOEXP; do
+for V in NOMFMA NOEXP NOSTAGE; do
   v=$(echo $V | tr A-Z a-z)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DNDEBUG -mllvm -amdgpu-mfma-vgpr-form=1 \
     -fno-honor-nans -DDD_DBG_$V -c $R/dualdiff_amd/csrc/attention.hip -o /tmp/attn_$v.o &
 done
 wait
-for v in nomfma noexp; do
+for v in nomfma noexp nostage; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libdd_attn_$v.so $L/obj/gemm.o $L/obj/norm.o /tmp/attn_$v.o $L/obj/elementwise.o
 done
 ls -la $L/*.so
