@@ -284,7 +284,7 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
     from dualdiff_amd.pipeline.pipeline_bev_controlnet import BEVDenoiser
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
     unet, cns = build_models(dtype, device, frames=args.frames, fp8=args.fp8_weights, lora_rank=args.lora_rank)
-    kw, pairs, shard_desc = {}, 1, None
+    kw, pairs, shard_desc, shard_msg = {}, 1, None, None
     graph = not args.no_graph
     if args.parallelism == "cfg-split":
         if dist is None or world % 2:
@@ -308,6 +308,15 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
         pairs = world                                  # the whole job advances ONE scene
         graph = graph and os.environ.get("DD_VIEW_SPLIT_GRAPH") == "1"     # p2p inside a captured graph: opt-in
         shard_desc = "views %s of CFG half %s" % (plan.local, "both" if plan.half is None else plan.half)
+        # bytes this rank sends / receives per UNet forward: 16 transformer blocks = 5 x (1400 tokens, 320 ch),
+        # 5 x (350, 640), 5 x (91, 1280), 1 x (28, 1280); K and V of every exchanged view-instance
+        nbat = args.scenes * args.frames * (1 if plan.cfg_split else 2)
+        sent = recv = 0
+        for nblk, (ntok, ch) in ((5, (1400, 320)), (5, (350, 640)), (5, (91, 1280)), (1, (28, 1280))):
+            s_, r_ = plan.message_bytes(ntok, ch, nb=nbat)
+            sent, recv = sent + nblk * s_, recv + nblk * r_
+        shard_msg = {"rank0_sent_bytes_per_forward": sent, "rank0_received_bytes_per_forward": recv,
+                     "exchanges_per_forward": 16, "views_per_rank": [len(v) for v in plan.views_of]}
     den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
                       hoist_invariant=args.hoist_invariant, use_graph=graph,
                       parallel_branches=not args.serial_branches, **kw)
@@ -375,6 +384,9 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
             total_ms = sum(r["ms_per_step"] for r in rows)
             top.update({"peak": PEAK_HBM_GBPS if top["bound"] == "hbm" else PEAK_MFMA_TFLOPS,
                         "event_overhead_us_subtracted": timer.overhead_ms * 1e3,
+                        "event_overhead_method": "measured at run time: median bracket around a %.1f us probe kernel minus "
+                                                 "its back-to-back time; empty bracket = %.1f us (add it back to undo)"
+                                                 % (timer.probe_ms * 1e3, timer.empty_bracket_ms * 1e3),
                         "share_of_timed_kernels": top["ms_per_step"] / total_ms,
                         "timed_kernels_ms_per_step": total_ms, "pmc_table": table_name,
                         "tuned_table": os.path.relpath(args.tune_cache or O.TUNE_TABLE_PATH, ROOT),
@@ -389,12 +401,54 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
     del den, unet, cns
     torch.cuda.empty_cache()
     return {"elapsed": elapsed, "finite": finite, "roofline": roofline, "graph": graph, "pairs": pairs,
-            "shard": shard_desc}
+            "shard": shard_desc, "shard_msg": shard_msg}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _self_launch(n, argv):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks OURSELVES, as the reference's
+    multi-GPU tools do (tools/downstream_v3_batched.py:287 `mp.spawn(..., nprocs=world_size)`), through
+    `python -m torch.distributed.run` as a CHILD process.  This parent has made no GPU call (importing torch and
+    parsing arguments initialise nothing), it never exec()s, and it exits with the child's code; the children get
+    fresh RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and each takes its own GPU."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _plumbing_check(args, world, rank):
+    """Launcher / rendezvous check WITHOUT the measured path (runs on a CPU-only host: tests/test_distributed_cpu.py):
+    every rank joins a gloo group, passes the barrier the timed region uses and takes the max-over-ranks of a fake
+    elapsed time; rank 0 prints a line with `n_gpus` = the world size and NO value — never a measurement."""
+    import torch.distributed as dist
+    from dualdiff_amd.parallel import max_over_ranks
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    slowest = max_over_ranks(1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"metric": _metric_name(), "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "plumbing_check": True,
+                          "slowest_rank_seconds": slowest, "requested_gpus": args.gpus}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE under torchrun, else 1); N > 1 outside torchrun "
+                         "makes this process the launcher of N child ranks")
     ap.add_argument("--steps", type=int, default=50, help="timed denoising steps (default: one 50-step DDIM sample)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
@@ -430,11 +484,22 @@ def main():
     ap.add_argument("--retune", action="store_true",
                     help="ignore the tracked table, time every shape again and write the result to --tune-cache "
                          "(default target: dualdiff_amd/tuned/gfx950.json, merged with its other entries)")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="launcher / rendezvous check only (gloo, no GPU call, no measurement): prints n_gpus")
     args = ap.parse_args()
 
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: this process becomes the launcher of N fresh ranks and touches no GPU itself
+        raise SystemExit(_self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.plumbing_check:
+        return _plumbing_check(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
                          "there is no CPU fallback for the measured path")
@@ -505,6 +570,13 @@ def main():
         "roofline": res["roofline"],
         "cpu_baseline": cpu,
     }
+    if args.parallelism == "view-split":
+        out["config"]["view_split"] = dict(res["shard_msg"] or {}, rank0_shard=res["shard"],
+                                           verified_on_multi_gpu_hardware=False,
+                                           note="RCCL device path of the neighbour K/V exchange has never run on >= 2 "
+                                                "GPUs in this build's reach (tests: gloo ranks, in-process shards on one "
+                                                "GPU; tests/test_parity_r03_gpu.py::test_view_split_two_ranks_rccl runs "
+                                                "where >= 2 GPUs exist); treat the number as unverified")
     if other is not None:
         ov = args.steps * scenes_total / other["elapsed"]
         out["other_dtype"] = {"dtype": other_name, "value": ov, "unit": "steps/s",

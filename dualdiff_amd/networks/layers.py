@@ -194,8 +194,12 @@ class LayerNorm(nn.Module):
 
     def run(self, x2d):
         hit = getattr(x2d, "_ln_cache", None)          # LayerNorm already emitted by the producer's epilogue
-        if hit is not None and hit[0] is self:
-            return hit[1]
+        if hit is not None:
+            # consumed ONCE: the kernels write through data_ptr (out=, accumulate), so tensor._version cannot
+            # tell whether x2d was rewritten later — a second LayerNorm of the same Python tensor recomputes
+            del x2d._ln_cache
+            if hit[0] is self:
+                return hit[1]
         return O.layernorm(x2d, self.weight, self.bias, self.eps)
 
     def forward(self, x):
@@ -248,6 +252,8 @@ LN_PRODUCER = __import__("os").environ.get("DD_LN_PRODUCER", "1") != "0"
 
 def ln_producer_ok(lin, norm, kw):
     if not LN_PRODUCER or not isinstance(norm, LayerNorm) or lin.out_features != 320 or lin.fp8:
+        return False
+    if LN_FOLD != "0" or LN_DIRECT:            # the consumer would fold / recompute the LayerNorm and ignore ln_out
         return False
     if lin.w2d.shape[1] % 64 or kw.get("a2") is not None and kw["a2"].shape[1] % 64:
         return False

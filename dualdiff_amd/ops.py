@@ -26,16 +26,21 @@ class KernelTimer:
         self.records = []
         self.shapes = shapes
         self.overhead_ms = 0.0
+        self.empty_bracket_ms = 0.0
+        self.probe_ms = 0.0
 
     def calibrate(self, n=64):
-        """Event overhead per bracket, subtracted in summary() so that the per-kernel averages are comparable
-        with rocprofv3's kernel durations.  An EMPTY bracket measures 4.6-4.8 us on MI355X; around a real kernel
-        the closing event's processing partly overlaps the kernel, and the bracket exceeds rocprofv3's duration
-        by 1.2-4.6 us (round-2 profile of the same build, kernels of 14-50 us: profiles/r02_kernel_stats_eager.csv
-        against roofline.classes of profiles/r02_bench.json; mean 3.0 us, the dominant direct conv 3.0 us) —
-        three quarters of the empty bracket (3.5 us) is subtracted.  Kernels of ~5 us (LayerNorm) stay
-        over-measured by the bracket; they are HBM/launch-bound classes, not the dominant one."""
+        """Event overhead per bracket, MEASURED at run time (not a fitted constant) and subtracted in
+        summary() so that the per-kernel averages are comparable with rocprofv3's kernel durations.
+
+        A probe kernel of ~10-15 us (dd_add over 8 Mi elements, L2-resident after the first pass) is launched
+        n times back to back inside ONE bracket -> its true per-launch time d (the single bracket's overhead is
+        amortised over n launches), then n times with a bracket around every launch -> b.  overhead = median(b) - d
+        is what a bracket adds around a real kernel while the queue is busy — the situation of the instrumented
+        step.  The empty-bracket figure (4.6-4.8 us on MI355X, of which ~3.5 us overlap a real kernel) is kept in
+        `empty_bracket_ms` for the JSON line; kernels of ~5 us stay the least certain rows of the table."""
         st = torch.cuda.current_stream()
+        dev = torch.device("cuda", torch.cuda.current_device())
         pairs = []
         for _ in range(n):
             e0 = torch.cuda.Event(enable_timing=True)
@@ -45,7 +50,33 @@ class KernelTimer:
             pairs.append((e0, e1))
         torch.cuda.synchronize()
         d = sorted(a.elapsed_time(b) for a, b in pairs)
-        self.overhead_ms = 0.75 * d[len(d) // 2]
+        self.empty_bracket_ms = d[len(d) // 2]
+        saved = _TIMER
+        set_timer(None)
+        try:
+            x = torch.ones(8 << 20, dtype=torch.float16, device=dev)
+            y = torch.empty_like(x)
+            for _ in range(8):
+                add(x, x, out=y)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(n):
+                add(x, x, out=y)
+            e1.record(st)
+            pairs = []
+            for _ in range(n):
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(st)
+                add(x, x, out=y)
+                a1.record(st)
+                pairs.append((a0, a1))
+            torch.cuda.synchronize()
+            true_ms = e0.elapsed_time(e1) / n
+            b = sorted(p.elapsed_time(q) for p, q in pairs)
+            self.probe_ms = true_ms
+            self.overhead_ms = min(max(b[len(b) // 2] - true_ms, 0.0), self.empty_bracket_ms)
+        finally:
+            set_timer(saved)
         return self.overhead_ms
 
     def start(self):
@@ -345,6 +376,14 @@ def _timed_gemm(lib, d, what, suffix, flops, nbytes, rows, n):
     d.phase = 0
 
 
+def _forget_derived(t):
+    """A tensor that is about to be (re)written through its data pointer loses whatever an earlier producer
+    attached to it (LayerNorm emitted by an epilogue, row statistics): those describe the OLD contents."""
+    for a in ("_ln_cache", "_ln_out", "_ln_stats"):
+        if hasattr(t, a):
+            delattr(t, a)
+
+
 def _rows2d(t):
     if t.dim() != 2 or t.stride(1) != 1:
         raise ValueError("expected a 2-D tensor with unit inner stride, got shape %s stride %s"
@@ -398,6 +437,8 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         out = torch.empty((rows, n), dtype=odt, device=a.device)
     elif out.dtype != odt:
         raise TypeError("gemm: out must be %s" % odt)
+    else:
+        _forget_derived(out)
     d = GemmDesc()
     d.out_f32 = int(bool(out_f32))
     if hm_out is not None:
@@ -521,6 +562,8 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     rows = m * hout * wout
     if out is None:
         out = torch.empty((rows, cout), dtype=x.dtype, device=x.device)
+    else:
+        _forget_derived(out)
     if thin_conv_ok(cin, cout, stride, m) and up_size is None and rowvec is None and res is None and alpha == 1.0 \
             and not accumulate and epilogue in (DD_EPI_NONE, DD_EPI_SILU) and tile == 0 and split_k == 0 \
             and out.is_contiguous():
@@ -695,6 +738,8 @@ def add(a, b, c=None, out=None):
     _need_gpu(a, b, c, out)
     if out is None:
         out = torch.empty_like(a)
+    else:
+        _forget_derived(out)
     e0 = _TIMER.start() if _TIMER is not None else None
     rc = lib.dd_add(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _dt(a), _stream())
     _native.check(rc, "add")

@@ -88,9 +88,11 @@ class BEVDenoiser:
         # scene; the ControlNet branches and everything per-instance run on those, attn4 fetches the
         # neighbour views' K/V from the other ranks (dualdiff_amd.parallel.ViewShard).  set_inputs() takes the
         # FULL n_cam-view inputs and keeps this rank's slice.  Composes with cfg_half.
-        self.view_shard = view_shard
-        if view_shard is not None or hasattr(unet, "set_view_shard"):
+        # A shard installed directly on the UNet (INTEGRATION.md "drop-in level": unet.set_view_shard(...)) is
+        # ADOPTED, never silently removed, when the argument is left out.
+        if view_shard is not None:
             unet.set_view_shard(view_shard)
+        self.view_shard = view_shard if view_shard is not None else getattr(unet, "view_shard", None)
 
     # ---------------------------------------------------------------------------- inputs ----
     def set_inputs(self, latents, prompt_embeds, camera_param, bboxes_list, conds):

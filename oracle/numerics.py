@@ -49,7 +49,12 @@ def _round_tree(x, dtype):
 
 
 @contextlib.contextmanager
-def storage_emulation(module, dtype):
+def storage_emulation(module, dtype, legacy=False):
+    """legacy=True: the ROUND-1 yardstick — only tensors that enter / leave a module are rounded; attention
+    probabilities and the functional residual-stream ops stay fp32 (prob_round / stor are identities).  Kept so
+    that tests can log the older, SMALLER floor beside the current one and hold e(HIP) <= 1.5 x that floor as
+    well: a regression cannot hide behind the round-2 redefinition of the yardstick.  FROZEN since round 2: any
+    further change to what this emulation rounds must be listed in DESIGN.md with before / after floors."""
     handles = []
 
     def pre(_m, args, kwargs):
@@ -65,7 +70,7 @@ def storage_emulation(module, dtype):
     for m in module.modules():
         handles.append(m.register_forward_pre_hook(pre, with_kwargs=True))
         handles.append(m.register_forward_hook(post))
-    saved, _PROB_DTYPE = _PROB_DTYPE, dtype
+    saved, _PROB_DTYPE = _PROB_DTYPE, (None if legacy else dtype)
     try:
         yield module
     finally:

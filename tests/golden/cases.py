@@ -205,8 +205,11 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32) if t.is_floating_point() else t
 
 
-def step_inputs(b=2):
-    """(uncond, cond) rows of every conditioning input, rounded to bf16-representable values."""
+def step_inputs(b=2, nbox=None, ltxt=None):
+    """(uncond, cond) rows of every conditioning input, rounded to bf16-representable values.  nbox / ltxt default
+    to the short token lists of the minted trajectory (5 boxes, 9 text tokens); the bench-context case passes the
+    bench workload's 20 boxes / 77 text tokens (Lc = 1 + 77 + 20 = 98)."""
+    STEP_NBOX, STEP_LTXT = (nbox or globals()["STEP_NBOX"]), (ltxt or globals()["STEP_LTXT"])
     g = torch.Generator().manual_seed(7)
     return {
         "sample": bf16_round(seeded_tensor((b, N_CAM, 4, H, W), 11)),

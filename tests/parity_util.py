@@ -1,17 +1,25 @@
 """Shared reporting of the end-to-end parity tests: metric, bound, and the tracked error table.
 
 Metric: relative L2 error e(y) = ||y - ref||_2 / ||ref||_2 against the fp32 CPU oracle.
-Bound:  e(HIP) <= max(1e-3, 1.1 * e_floor) where e_floor is the error of the oracle itself when every
-inter-module tensor is rounded to the storage dtype (oracle/numerics.py) — north_star's 1e-3 wherever the
-storage dtype allows it, and at most 10 % above the reference dtype's own rounding noise elsewhere.
-Every comparison appends `name, dtype, e_hip, e_floor, bound` to the CSV named by DD_PARITY_CSV
-(default gpurun_out/r02_parity.csv; the copy judged is profiles/r02_parity.csv).
+Bound:  e(HIP) <= max(1e-3, 1.0 * e_floor) where e_floor is the error of the oracle itself when every
+inter-module tensor is rounded to the storage dtype (oracle/numerics.py, frozen since round 2) — north_star's
+1e-3 wherever the storage dtype allows it, and NEVER above the reference dtype's own rounding noise elsewhere
+(round 2 allowed 1.1 x; VERDICT r2 weak #1b).
+Besides that, every row logs
+  * e_vs_emul = ||y_hip - y_emul|| / ||y_emul||: the metric north_star states literally (HIP fp16 output vs the
+    reference's fp16 output, here the storage-emulated oracle).  Two independent roundings of the same depth
+    differ by about sqrt(2) x the floor, so this column is reported, not bounded at 1e-3;
+  * e_floor_r1: the ROUND-1 floor (module-boundary rounding only, `storage_emulation(legacy=True)`) where the
+    test computes it, and then ALSO requires e(HIP) <= 1.5 x e_floor_r1 — the round-1 acceptance rule, so
+    the redefinition of the yardstick in round 2 cannot hide a regression.
+CSV: DD_PARITY_CSV (default gpurun_out/r03_parity.csv; the copy judged is profiles/r03_parity.csv).
 """
 import os
 
 import torch
 
-FLOOR_SLACK = 1.1
+FLOOR_SLACK = 1.0
+LEGACY_SLACK = 1.5
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -25,28 +33,36 @@ def rel_l2(y, ref):
 
 
 def _csv_path():
-    return os.environ.get("DD_PARITY_CSV", os.path.join(_ROOT, "gpurun_out", "r02_parity.csv"))
+    return os.environ.get("DD_PARITY_CSV", os.path.join(_ROOT, "gpurun_out", "r03_parity.csv"))
 
 
-def log_row(name, dtype, e_hip, e_floor, bnd):
+def log_row(name, dtype, e_hip, e_floor, bnd, e_vs_emul=float("nan"), e_floor_r1=float("nan")):
     path = _csv_path()
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         new = not os.path.exists(path)
         with open(path, "a") as f:
             if new:
-                f.write("name,dtype,e_hip,e_floor,bound\n")
-            f.write("%s,%s,%.4e,%.4e,%.4e\n" % (name.replace(",", ";"), str(dtype).split(".")[-1], e_hip, e_floor, bnd))
+                f.write("name,dtype,e_hip,e_floor,bound,e_hip_vs_emul,e_floor_r1\n")
+            f.write("%s,%s,%.4e,%.4e,%.4e,%.4e,%.4e\n" % (name.replace(",", ";"), str(dtype).split(".")[-1], e_hip,
+                                                         e_floor, bnd, e_vs_emul, e_floor_r1))
     except OSError:
         pass
 
 
-def report(name, y, ref, dtype, record, emul=None):
-    """Prints and logs e(HIP) and the reference-dtype noise floor; returns e(HIP) / bound."""
+def report(name, y, ref, dtype, record, emul=None, emul_legacy=None):
+    """Prints and logs e(HIP), the reference-dtype noise floor, e(HIP vs emulated reference) and (optionally) the
+    round-1 floor; returns max(e(HIP) / bound, e(HIP) / (1.5 x round-1 floor)) — the caller asserts <= 1."""
     e = rel_l2(y, ref)
     fl = rel_l2(emul, ref) if emul is not None else 0.0
-    print("%-40s %-8s e_hip=%.3e  e_floor=%.3e  bound=%.3e" % (name, str(dtype).split(".")[-1], e, fl, bound(fl)))
+    ee = rel_l2(y, emul) if emul is not None else float("nan")
+    fl1 = rel_l2(emul_legacy, ref) if emul_legacy is not None else float("nan")
+    print("%-40s %-8s e_hip=%.3e  e_floor=%.3e  bound=%.3e  e_vs_emul=%.3e  e_floor_r1=%.3e"
+          % (name, str(dtype).split(".")[-1], e, fl, bound(fl), ee, fl1))
     record.append((name, e, fl))
-    log_row(name, dtype, e, fl, bound(fl))
+    log_row(name, dtype, e, fl, bound(fl), ee, fl1)
     assert torch.isfinite(y).all(), name
-    return e / bound(fl)
+    ratio = e / bound(fl)
+    if emul_legacy is not None:
+        ratio = max(ratio, e / max(1e-3, LEGACY_SLACK * fl1))
+    return ratio

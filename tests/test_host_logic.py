@@ -215,3 +215,43 @@ def test_unet_imports_a_foreign_diffusers_checkpoint(tmp_path, fmt):
         os.remove(st)
     with pytest.raises(RuntimeError, match="missing keys"):
         UNet2DConditionModelMultiview.from_pretrained(str(tmp_path), subfolder="unet")
+
+
+def test_fold_lora_key_validation_and_alpha():
+    """fold_lora_ must reject malformed / incomplete LoRA dicts with a clear error and honour
+    network_alpha (delta = scale * alpha / rank * up @ down)."""
+    from dualdiff_amd.lora import fold_lora_, lora_keys
+    from dualdiff_amd.networks.layers import Attention, seeded_init_
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn1 = Attention(64, None, heads=2, dim_head=32)
+
+    net = seeded_init_(Holder(), 5)
+    w0 = net.attn1.to_q.weight.detach().clone()
+    g = torch.Generator().manual_seed(1)
+    lora = {k: torch.randn(shape, generator=g) * 0.1 for k, shape in lora_keys(net, rank=4).items()}
+    assert len(lora) == 8
+    down, up = lora["attn1.processor.to_q_lora.down.weight"], lora["attn1.processor.to_q_lora.up.weight"]
+    assert fold_lora_(net, lora, 0.5) == 4
+    assert torch.allclose(net.attn1.to_q.weight, w0 + 0.5 * up @ down, atol=1e-6)
+    # network_alpha: alpha / rank scales the delta
+    net2 = seeded_init_(Holder(), 5)
+    lora_a = dict(lora)
+    lora_a["attn1.processor.to_q_lora.alpha"] = torch.tensor(8.0)
+    fold_lora_(net2, lora_a, 0.5)
+    assert torch.allclose(net2.attn1.to_q.weight, w0 + 0.5 * (8.0 / 4) * up @ down, atol=1e-6)
+    assert torch.allclose(net2.attn1.to_k.weight, net.attn1.to_k.weight)        # other projections: alpha absent -> 1
+    # incomplete / malformed dictionaries fail loudly and touch nothing
+    net3 = seeded_init_(Holder(), 5)
+    for bad, exc in (({k: v for k, v in lora.items() if not k.endswith("to_q_lora.up.weight")}, KeyError),
+                     ({k: v for k, v in lora.items() if not k.endswith("to_q_lora.down.weight")}, KeyError),
+                     ({**lora, "attn1.to_q.weight": w0}, KeyError),
+                     ({"attn9.processor.to_q_lora.down.weight": down, "attn9.processor.to_q_lora.up.weight": up}, KeyError),
+                     ({"attn1.processor.to_x_lora.down.weight": down, "attn1.processor.to_x_lora.up.weight": up}, KeyError),
+                     ({"attn1.processor.to_q_lora.down.weight": down[:, :32],
+                       "attn1.processor.to_q_lora.up.weight": up}, ValueError)):
+        with pytest.raises(exc):
+            fold_lora_(net3, bad)
+    assert torch.equal(net3.attn1.to_q.weight, w0)
