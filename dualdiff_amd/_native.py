@@ -10,7 +10,7 @@ import os
 # and the process must end up with ONE HIP runtime (ours resolves to the already-loaded soname);
 # loading ours first gives two runtimes and every launch on a torch stream fails.
 import torch  # noqa: F401
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p)
 
 from . import _build
 
@@ -36,6 +36,7 @@ class GemmDesc(Structure):
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("w_scale", c_void_p),
         ("phase", c_int32),
         ("ln_out", c_void_p), ("ld_ln_out", c_int64), ("lno_gamma", c_void_p), ("lno_beta", c_void_p),
+        ("splitk_inkernel", c_int32),
     ]
 
 
@@ -74,6 +75,7 @@ SIGNATURES = {
     "dd_attention": (c_int32, [POINTER(AttnDesc), c_void_p]),
     "dd_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_scale": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p]),
+    "dd_probe_spin": (c_int32, [c_void_p, c_uint32, c_void_p]),
     "dd_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

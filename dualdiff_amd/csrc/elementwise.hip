@@ -623,6 +623,28 @@ extern "C" int dd_cfg_unipc_step(const void* eps, const void* x, void* x_out, vo
   return dd_check_launch();
 }
 
+// Timing probe (bench.py's KernelTimer calibration): ONE wave that waits `ticks` ticks of the constant 100 MHz
+// s_memrealtime counter and records its own first / last reading -> a kernel whose device-side duration is known
+// independently of events, rocprofv3 and launch gaps.
+namespace {
+__global__ __launch_bounds__(64) void dd_probe_spin_kernel(uint64_t* stamps, uint32_t ticks) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t t1 = t0;
+  while (t1 - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(4);
+    t1 = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0) { stamps[0] = t0; stamps[1] = t1; }
+}
+}  // namespace
+
+extern "C" int dd_probe_spin(uint64_t* stamps, uint32_t ticks_100mhz, dd_stream_t stream) {
+  if (!stamps || ticks_100mhz == 0 || ticks_100mhz > 100000000u) return DD_ERR_BAD_ARG;
+  dd_clear_error();
+  hipLaunchKernelGGL(dd_probe_spin_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), stamps, ticks_100mhz);
+  return dd_check_launch();
+}
+
 extern "C" int dd_abi_version(void) { return DD_ABI_VERSION; }
 extern "C" const char* dd_target_arch(void) { return "gfx950"; }
 extern "C" const char* dd_error_string(int code) {

@@ -41,6 +41,7 @@ struct GemmParams {
   int band_rows, bands; float inv_bands; // ... its BAND form: output pixels per band, bands per instance
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
   int* tile_counters;                    // split-K: per-tile arrival counters (in-kernel ordered reduction) or NULL
+  uint32_t partial_bytes;                // extent of the slab region (buffer descriptor of the sc1 slab path)
   int out_f32;                           // store fp32 instead of T
   float* stat_out;                       // [rows][n/32][2] row sum / sum of squares of the stored values, or NULL
   const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
@@ -139,7 +140,7 @@ template <typename T, int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
                                            int block_n0, int wave_m, int wave_n, int lane, int row_end,
                                            const float* ln_mean = nullptr, const float* ln_rstd = nullptr,
-                                           int tile_id = 0) {
+                                           int tile_id = 0, int* lds_flag = nullptr) {
   const int q = lane >> 4;
   const int c = lane & 15;
   const int row0 = block_m0 + wave_m * (TM * 16) + c;
@@ -211,7 +212,18 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
   } else {
     constexpr int NG = TN / 2;
     const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
-    if (p.partial) {                       // split-K slab: plain fp32 stores
+    if (p.partial) {                       // split-K slab: fp32 stores
+      // Two forms.  tile_counters == NULL: plain stores, dd_splitk_reduce_kernel (a second launch) adds the slabs and
+      // runs the epilogue.  tile_counters != NULL: IN-LAUNCH ordered reduction by the K-slice that arrives last at
+      // the tile's counter — the write-through recipe of the CDNA4 guide (cdna_hip_programming.md "In-launch split-K
+      // reduction", MI355X_MICROARCH.md "inter-workgroup visibility"): the slabs are stored sc1 (write-through, no
+      // release fence: the L2s of the 8 XCDs are not coherent and a buffer_wbl2 per workgroup costs more than the
+      // second launch — the round-1 form with __threadfence() ran 32 -> 66 us on the 4x7 conv), EVERY storing wave
+      // drains its stores (s_waitcnt vmcnt(0)), the workgroup barrier, ONE lane's relaxed agent-scope ticket; the
+      // workgroup whose add returns split-1 reads all slabs with sc1 loads (L1-bypassing; every load of the handed-off
+      // bytes) in slice order — bit-identical to the two-launch form whoever is last — and runs the epilogue.
+      const bool ink = p.tile_counters != nullptr;
+      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.partial_bytes, 0x00020000);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int row = row0 + tm * 16;
@@ -220,28 +232,28 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         for (int g8 = 0; g8 < NG; ++g8) {
           const int col = col0 + g8 * 8;
           if (col >= p.n) continue;
-          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
-          *reinterpret_cast<f32x4*>(dst) = acc[g8 * 2][tm];
-          *reinterpret_cast<f32x4*>(dst + 4) = acc[g8 * 2 + 1][tm];
+          if (ink) {
+            const uint32_t off = (uint32_t)((((int64_t)blockIdx.z * p.rows + row) * p.n + col) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[g8 * 2][tm]), rs_p, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[g8 * 2 + 1][tm]), rs_p, off + 16, 0, 16);
+          } else {
+            float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
+            *reinterpret_cast<f32x4*>(dst) = acc[g8 * 2][tm];
+            *reinterpret_cast<f32x4*>(dst + 4) = acc[g8 * 2 + 1][tm];
+          }
         }
       }
-      if (!p.tile_counters) return;        // two-launch mode: dd_splitk_reduce_kernel runs the epilogue
-      // In-kernel ORDERED reduction: the K-slice that arrives last at the tile's counter adds all the
-      // slabs in slice order (bit-reproducible, whoever is last) and runs the epilogue — no second
-      // launch.  The slabs of one tile are written from different XCDs whose L2s are not coherent
-      // with each other: device-scope release (L2 write-back) before the counter, acquire
-      // (invalidate) after it.
-      __shared__ int s_last;
-      __threadfence();
-      __syncthreads();
+      if (!ink) return;                    // two-launch mode: dd_splitk_reduce_kernel runs the epilogue
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores have landed
+      __syncthreads();                                      // ... and every wave is past its last LDS read
       if (threadIdx.x == 0) {
-        const int prev = atomicAdd(p.tile_counters + tile_id, 1);
-        s_last = prev == (int)gridDim.z - 1;
-        if (s_last) p.tile_counters[tile_id] = 0;      // ready for the next launch (stream-ordered)
+        const int prev = __hip_atomic_fetch_add(p.tile_counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.z - 1;
+        if (last) __hip_atomic_store(p.tile_counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stream-ordered next launch
+        *lds_flag = last;
       }
       __syncthreads();
-      if (!s_last) return;
-      __threadfence();
+      if (!*lds_flag) return;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int rowc = min(row0 + tm * 16, p.rows - 1);
@@ -249,10 +261,11 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         for (int g8 = 0; g8 < NG; ++g8) {
           const int colc = min(col0 + g8 * 8, p.n - 8);
           f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+          const uint32_t off0 = (uint32_t)(((int64_t)rowc * p.n + colc) * 4);
+          const uint32_t zstride = (uint32_t)((int64_t)p.rows * p.n * 4);
           for (int z = 0; z < (int)gridDim.z; ++z) {
-            const float* src = p.partial + ((int64_t)z * p.rows + rowc) * p.n + colc;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, off0 + (uint32_t)z * zstride, 0, 16));
+            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, off0 + (uint32_t)z * zstride + 16, 0, 16));
             s0[0] += a[0]; s0[1] += a[1]; s0[2] += a[2]; s0[3] += a[3];
             s1[0] += b[0]; s1[1] += b[1]; s1[2] += b[2]; s1[3] += b[3];
           }
@@ -566,7 +579,8 @@ void dd_gemm_kernel(const GemmParams p) {
     buf ^= 1;
   }
 
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile);
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile,
+                               reinterpret_cast<int*>(smem));
 }
 
 // =============================================================================================
@@ -1053,7 +1067,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   }
   const bool ln = !CONV && p.ln_colsum;
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
-                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr, tile);
+                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr, tile, reinterpret_cast<int*>(smem));
   if (!have_next) break;
   lin += (int)gridDim.x;                   // next tile of this workgroup; its first stages are already in flight
   tile = xcd_remap(lin, ntiles);
@@ -1408,7 +1422,7 @@ void dd_conv3s_kernel(const GemmParams p) {
   }
   // rows past the tile's instances are padding
   store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows),
-                               nullptr, nullptr, tile);
+                               nullptr, nullptr, tile, reinterpret_cast<int*>(smem));
 #ifdef DD_DBG_STAMP
   DD_STAMP(5);
   if (threadIdx.x == 0 && p.dbg_stamps) {
@@ -2239,9 +2253,13 @@ constexpr int64_t DD_COUNTER_BYTES = 65536;
 // In-kernel reduction is OFF by default: the device-scope release / acquire it needs (the L2s of the
 // 8 XCDs are not coherent: buffer_wbl2 + buffer_inv per workgroup) costs far more than the second
 // launch — 4x7 conv 32 -> 66 us, whole step 73.5 -> 69.1 steps/s.  DD_SPLITK_INKERNEL=1 enables it.
-bool inkernel_reduce(const Plan& pl) {
-  static const bool on = getenv("DD_SPLITK_INKERNEL") && atoi(getenv("DD_SPLITK_INKERNEL")) == 1;
-  return on && (int64_t)pl.tiles_m * pl.tiles_n * (int64_t)sizeof(int) <= DD_COUNTER_BYTES;
+bool inkernel_reduce(const dd_gemm_desc* d, const Plan& pl) {
+  // per call: dd_gemm_desc.splitk_inkernel (the tuner times both forms); DD_SPLITK_INKERNEL=1 / 0 forces it on / off
+  static const int force = getenv("DD_SPLITK_INKERNEL") ? atoi(getenv("DD_SPLITK_INKERNEL")) : -1;
+  const bool want = force >= 0 ? force == 1 : d->splitk_inkernel != 0;
+  const int64_t slab_bytes = (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
+  return want && slab_bytes < ((int64_t)1 << 32) &&
+         (int64_t)pl.tiles_m * pl.tiles_n * (int64_t)sizeof(int) <= DD_COUNTER_BYTES;
 }
 
 extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
@@ -2265,18 +2283,18 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   if (t.stages < 0) {
     const bool band = t.stages == -3;
     const int nsw = (t.id == 31 || band) ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4)));
-    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
+    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d ink=%d grid=%dx%d tile=%s",
              d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, nsw, (t.id >= 37 && !band) ? 3 : 1,
-             band ? "true" : "false", pl.split, pl.tiles_m, pl.tiles_n, t.name);
+             band ? "true" : "false", pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)), pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
   char stage[16] = "";
   if (t.stages) snprintf(stage, sizeof(stage), " %d,", t.stages);
-  snprintf(g_kname, sizeof(g_kname), "dd_gemm%s_kernel<%s, %d, %d, %d, %d,%s %s, %s> split=%d grid=%dx%d tile=%s",
+  snprintf(g_kname, sizeof(g_kname), "dd_gemm%s_kernel<%s, %d, %d, %d, %d,%s %s, %s> split=%d ink=%d grid=%dx%d tile=%s",
            t.stages ? "2" : "", d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, stage,
            d->conv ? "true" : "false", d->epilogue == DD_EPI_GEGLU ? "true" : "false",
-           pl.split, pl.tiles_m, pl.tiles_n, t.name);
+           pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)), pl.tiles_m, pl.tiles_n, t.name);
   return g_kname;
 }
 
@@ -2345,7 +2363,8 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
     const int64_t need = DD_COUNTER_BYTES + (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
     if (!d->ws || d->ws_bytes < need) return DD_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ws) + DD_COUNTER_BYTES);
-    if (inkernel_reduce(pl)) p.tile_counters = reinterpret_cast<int*>(d->ws);
+    p.partial_bytes = (uint32_t)std::min<int64_t>((int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float), 0xFFFFFFFFll);
+    if (inkernel_reduce(d, pl)) p.tile_counters = reinterpret_cast<int*>(d->ws);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();

@@ -29,16 +29,19 @@ class KernelTimer:
         self.empty_bracket_ms = 0.0
         self.probe_ms = 0.0
 
-    def calibrate(self, n=64):
+    def calibrate(self, n=48, probe_us=15.0):
         """Event overhead per bracket, MEASURED at run time (not a fitted constant) and subtracted in
         summary() so that the per-kernel averages are comparable with rocprofv3's kernel durations.
 
-        A probe kernel of ~10-15 us (dd_add over 8 Mi elements, L2-resident after the first pass) is launched
-        n times back to back inside ONE bracket -> its true per-launch time d (the single bracket's overhead is
-        amortised over n launches), then n times with a bracket around every launch -> b.  overhead = median(b) - d
-        is what a bracket adds around a real kernel while the queue is busy — the situation of the instrumented
-        step.  The empty-bracket figure (4.6-4.8 us on MI355X, of which ~3.5 us overlap a real kernel) is kept in
-        `empty_bracket_ms` for the JSON line; kernels of ~5 us stay the least certain rows of the table."""
+        Probe: dd_probe_spin — one wave that busy-waits `probe_us` on the constant 100 MHz s_memrealtime counter and
+        stores its own first and last reading, i.e. a kernel whose DEVICE-SIDE duration is known without events or a
+        profiler.  n such launches are bracketed like the kernels of the instrumented step (queue kept busy);
+        overhead = median(bracket - in-kernel duration): what an event pair adds around a ~15 us kernel (the
+        dominant classes are 15-45 us).  A first attempt subtracted a probe's back-to-back time instead; that time
+        contains the launch-to-launch gap a profiler does not count and gave 0.  The empty-bracket figure
+        (4.6-4.8 us on MI355X) is kept in `empty_bracket_ms` for the JSON line; kernels of ~5 us stay the least
+        certain rows of the table."""
+        lib = _native.load()
         st = torch.cuda.current_stream()
         dev = torch.device("cuda", torch.cuda.current_device())
         pairs = []
@@ -51,32 +54,23 @@ class KernelTimer:
         torch.cuda.synchronize()
         d = sorted(a.elapsed_time(b) for a, b in pairs)
         self.empty_bracket_ms = d[len(d) // 2]
-        saved = _TIMER
-        set_timer(None)
-        try:
-            x = torch.ones(8 << 20, dtype=torch.float16, device=dev)
-            y = torch.empty_like(x)
-            for _ in range(8):
-                add(x, x, out=y)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(st)
-            for _ in range(n):
-                add(x, x, out=y)
-            e1.record(st)
-            pairs = []
-            for _ in range(n):
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a0.record(st)
-                add(x, x, out=y)
-                a1.record(st)
-                pairs.append((a0, a1))
-            torch.cuda.synchronize()
-            true_ms = e0.elapsed_time(e1) / n
-            b = sorted(p.elapsed_time(q) for p, q in pairs)
-            self.probe_ms = true_ms
-            self.overhead_ms = min(max(b[len(b) // 2] - true_ms, 0.0), self.empty_bracket_ms)
-        finally:
-            set_timer(saved)
+        stamps = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+        ticks = int(probe_us * 100)
+        backlog = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        for _ in range(40):                       # keep the GPU behind the host while the brackets are enqueued
+            backlog.zero_()
+        pairs = []
+        for i in range(n):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(st)
+            _native.check(lib.dd_probe_spin(ctypes.c_void_p(stamps[i].data_ptr()), ticks, _stream()), "probe_spin")
+            a1.record(st)
+            pairs.append((a0, a1))
+        torch.cuda.synchronize()
+        inside = (stamps[:, 1] - stamps[:, 0]).double().cpu() * 1e-5          # 100 MHz ticks -> ms
+        over = sorted(p.elapsed_time(q) - float(inside[i]) for i, (p, q) in enumerate(pairs))
+        self.probe_ms = float(inside.median())
+        self.overhead_ms = min(max(over[len(over) // 2], 0.0), self.empty_bracket_ms)
         return self.overhead_ms
 
     def start(self):
@@ -119,6 +113,11 @@ _TILES = None           # filled from the library (dd_gemm_tile_id) on first use
 _SPLITS = (1, 2, 3, 4, 5, 6, 8, 12, 16)
 
 
+def _entry(v):
+    """(tile, split-K, split-K form): tables written before round 3 carry two values (form 0 = two launches)."""
+    return (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
+
+
 def tuned_table():
     return dict(_TUNED)
 
@@ -132,7 +131,7 @@ def save_tuned(path, merge=True):
     if merge and _os.path.exists(path):
         with open(path) as f:
             for k, v in json.load(f).get("entries", []):
-                entries[ast.literal_eval(k)] = (int(v[0]), int(v[1]))
+                entries[ast.literal_eval(k)] = _entry(v)
     entries.update(_TUNED)
     _os.makedirs(_os.path.dirname(_os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
@@ -151,12 +150,16 @@ def load_tuned(path):
     for k, v in blob["entries"]:
         key = ast.literal_eval(k)
         if key not in _TUNED:
-            _TUNED[key] = (int(v[0]), int(v[1]))
+            _TUNED[key] = _entry(v)
             n += 1
     return n
 
 
 _COLD = _os.environ.get("DD_AUTOTUNE_COLD", "1") != "0"
+# Offer the in-launch split-K reduction (dd_gemm_desc.splitk_inkernel) to the tuner: OFF by default — measured on the
+# step's 23 split-K shapes (tools/splitk_ab.py, cold weights) it is bit-identical but 3-80 % SLOWER than the second
+# launch (853 -> 1108 us summed): the last-arriving slice reads split x 32-96 KB of slabs alone at the cross-XCD rate.
+_INKERNEL = _os.environ.get("DD_TUNE_INKERNEL", "0") == "1"
 _FLUSH = {}
 
 # The tuned table of the shapes the denoising step touches is TRACKED (dualdiff_amd/tuned/gfx950.json,
@@ -204,20 +207,20 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
     if hit is not None:
         return hit
     if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
-        return 0, 0
-    saved = (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes)
+        return 0, 0, 0
+    saved = (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes, d.splitk_inkernel)
     scratch = torch.empty(out_shape, dtype=dtype, device=device)
     d.out, d.ldc, d.accumulate = scratch.data_ptr(), scratch.stride(0), 0
     kt = (d.k + 63) // 64
     blocks128 = ((d.rows + 127) // 128) * ((d.n + 127) // 128)
-    best, best_t = (0, 0), float("inf")
+    best, best_t = (0, 0, 0), float("inf")
     stream = _stream()
     global _TILES
     if _TILES is None:
         _TILES = tuple(lib.dd_gemm_tile_id(i) for i in range(lib.dd_gemm_num_tiles()))
 
-    def timed(tile, split, iters):
-        d.tile, d.split_k = tile, split
+    def timed(tile, split, iters, ink=0):
+        d.tile, d.split_k, d.splitk_inkernel = tile, split, ink
         need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
         if need > 0:
             ws = workspace(need, device)
@@ -251,16 +254,17 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
         for split in _SPLITS:
             if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):
                 continue
-            t = timed(tile, split, 3)            # >= 3 samples per candidate, cold or hot
-            if t is not None:
-                cands.append((t, tile, split))
+            for ink in ((0, 1) if split > 1 and _INKERNEL else (0,)):       # split-K: two launches / in-launch reduction
+                t = timed(tile, split, 3, ink)            # >= 3 samples per candidate, cold or hot
+                if t is not None:
+                    cands.append((t, tile, split, ink))
     # the coarse pass is noisy: re-time the front-runners with more launches
     cands.sort()
-    for t, tile, split in cands[:8]:
-        t2 = timed(tile, split, 15 if _COLD else 12)
+    for t, tile, split, ink in cands[:8]:
+        t2 = timed(tile, split, 15 if _COLD else 12, ink)
         if t2 is not None and t2 < best_t:
-            best, best_t = (tile, split), t2
-    (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
+            best, best_t = (tile, split, ink), t2
+    (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes, d.splitk_inkernel) = saved
     _TUNED[key] = best
     return best
 
@@ -329,7 +333,7 @@ def workspace(nbytes, device, kind="gemm"):
 def _kname(lib, d):
     full = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
     name, rest = full.split(" split=")
-    return name, int(rest.split(" ")[0])
+    return name, int(rest.split(" ")[0]), " ink=1" in rest
 
 
 def _staged_bytes(lib, d):
@@ -357,8 +361,13 @@ def _timed_gemm(lib, d, what, suffix, flops, nbytes, rows, n):
     """dd_gemm under the KernelTimer: a split-K GEMM's two launches are bracketed SEPARATELY (dd_gemm_desc.phase)
     and booked under their own kernel symbols, so that every class of the roofline table is one kernel symbol
     whose average duration can be checked against rocprofv3's."""
-    name, split = _kname(lib, d)
+    name, split, ink = _kname(lib, d)
     staged = _staged_bytes(lib, d)
+    if split > 1 and ink:        # ONE launch: partial slabs written through + read back by the last-arriving slices
+        e0 = _TIMER.start()
+        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
+        _TIMER.stop(e0, name + suffix, flops, nbytes + 8.0 * split * rows * n, staged)
+        return
     if split <= 1:
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
@@ -393,7 +402,7 @@ def _rows2d(t):
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
          out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
-         ln_stats=False, head_major=None, ln_direct=None, w_scale=None, ln_out=None):
+         ln_stats=False, head_major=None, ln_direct=None, w_scale=None, ln_out=None, splitk_inkernel=0):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
     head_major = (D, scaled_planes, scale): the result comes back as (n / D, rows, D) — one contiguous
     [rows][D] plane per head of a fused Q|K|V projection, the first `scaled_planes` planes multiplied by
@@ -460,7 +469,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     d.out = out.data_ptr(); d.ldc = out.stride(0)
     d.alpha = alpha; d.accumulate = int(accumulate); d.epilogue = epilogue
     d.conv = 0
-    d.dtype = _dt(a); d.tile = tile; d.split_k = split_k
+    d.dtype = _dt(a); d.tile = tile; d.split_k = split_k; d.splitk_inkernel = int(splitk_inkernel)
     if ln is not None:
         if bias is not None or a2 is not None:
             raise ValueError("gemm(ln=...) folds the bias and takes a single source")
@@ -508,7 +517,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         stats_out = torch.empty((rows, n // 32, 2), dtype=torch.float32, device=a.device)
         d.ln_stats_out = stats_out.data_ptr()
     if tile == 0 and split_k == 0:
-        d.tile, d.split_k = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
+        d.tile, d.split_k, d.splitk_inkernel = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
                                       + (("f32",) if out_f32 else ()) + (("so",) if ln_stats else ())
                                       + (("si",) if stats_in is not None else ())
                                       + (("hm", head_major[0]) if head_major is not None else ())
@@ -541,7 +550,7 @@ def thin_conv_ok(cin, cout, stride, m):
 
 
 def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res=None,
-            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0):
+            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, splitk_inkernel=0):
     """3x3 / pad 1 convolution as an implicit GEMM on an NHWC batch.
 
     x: (m*hin*win, cin); w: (cout, 9*cin) packed [cout][ky][kx][cin]; optional nearest
@@ -593,9 +602,9 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     d.conv = 1
     d.hin, d.win, d.cin, d.hv, d.wv = hin, win, cin, hv, wv
     d.hout, d.wout, d.stride = hout, wout, stride
-    d.dtype = _dt(x); d.tile = tile; d.split_k = split_k
+    d.dtype = _dt(x); d.tile = tile; d.split_k = split_k; d.splitk_inkernel = int(splitk_inkernel)
     if tile == 0 and split_k == 0:
-        d.tile, d.split_k = _autotune(lib, d, ("c", m, hin, win, cin, cout, stride, hv, wv, d.dtype),
+        d.tile, d.split_k, d.splitk_inkernel = _autotune(lib, d, ("c", m, hin, win, cin, cout, stride, hv, wv, d.dtype),
                                       (rows, cout), x.dtype, x.device, warm=(x, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0 or _DBG_STAMP_WS:

@@ -166,6 +166,12 @@ typedef struct dd_gemm_desc {
   int64_t ld_ln_out;
   const void* lno_gamma;
   const void* lno_beta;
+  /* split-K form (ignored when split-K is off): 0 = two launches (fp32 slabs, then dd_splitk_reduce_kernel adds them
+   * and runs the epilogue); 1 = ONE launch: the slabs are stored write-through (sc1), every K slice takes a ticket on
+   * the tile's arrival counter (the first 64 KiB of `ws`) and the slice that arrives last adds all slabs in slice
+   * order and runs the epilogue — bit-identical to form 0.  Tiles x 4 B must fit the counter region and the slab
+   * region must be < 4 GiB, else form 0 is used. */
+  int32_t splitk_inkernel;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
@@ -332,6 +338,11 @@ int dd_cfg_ddim_step(const void* eps, const void* x, void* x_out, void* x_dup,
 int dd_cfg_unipc_step(const void* eps, const void* x, void* x_out, void* x_dup, float* last, float* m1,
                       float* m2, const float* coef, float guidance, int64_t n, int32_t dtype,
                       dd_stream_t stream);
+
+/* Measurement aid (not on the data path): one wave busy-waits `ticks_100mhz` ticks of the constant-rate 100 MHz
+ * s_memrealtime counter and stores its first and last counter reading in stamps[0], stamps[1] (device memory).
+ * bench.py brackets it with HIP events to learn what an event pair adds to a kernel of KNOWN device-side duration. */
+int dd_probe_spin(uint64_t* stamps, uint32_t ticks_100mhz, dd_stream_t stream);
 
 #ifdef __cplusplus
 }

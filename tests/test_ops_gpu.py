@@ -947,3 +947,89 @@ def test_conv3x3_band_direct(ops, case, dtype):
     y1 = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, tile=39, split_k=1)
     y2 = ops.conv3x3(x, L.pack_conv_weight(w), b, m, h, w_, tile=39, split_k=1)
     assert torch.equal(y1, y2)
+
+
+# ------------------------------------------------------------------ split-K reduced inside the launch ----
+# dd_gemm_desc.splitk_inkernel = 1 (round 3): write-through (sc1) slabs + arrival ticket + ordered reduction by the
+# last-arriving K slice (CDNA4 guide recipe; the 8 XCD L2s are not coherent).  The sum order is the slice order in
+# both forms, so the result must be BIT-IDENTICAL to the two-launch form.  Hazards the tests provoke on purpose:
+# stale lines (the SAME workspace is re-used by back-to-back launches with different inputs, slabs of the previous
+# launch may sit in an L1 / L2), several tiles per CU, ragged tile rows / columns, arrival counters left non-zero.
+INK_DENSE = [(1092, 1280, 1280, 13, 2), (1092, 1280, 1280, 15, 4), (336, 1280, 1280, 13, 5), (336, 1280, 6400, 17, 8),
+             (1092, 3840, 1280, 44, 2), (4200, 640, 640, 15, 2), (16800, 320, 1600, 28, 3), (77, 72, 1024, 18, 4),
+             (200, 328, 2048, 12, 16), (1092, 1280, 5120, 20, 6)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,n,k,tile,split", INK_DENSE, ids=lambda v: str(v))
+def test_gemm_split_k_inkernel_bitwise(ops, dtype, rows, n, k, tile, split):
+    w = rnd((n, k), dtype, 2, k ** -0.5)
+    b = rnd((n,), dtype, 3)
+    for it in range(6):                              # different inputs through the same workspace, back to back
+        a = rnd((rows, k), dtype, 10 + it)
+        res = rnd((rows, n), dtype, 20 + it)
+        y2 = ops.gemm(a, w, b, res=res, tile=tile, split_k=split, splitk_inkernel=0)
+        y1 = ops.gemm(a, w, b, res=res, tile=tile, split_k=split, splitk_inkernel=1)
+        assert torch.equal(y1, y2), "in-launch reduction differs from the two-launch form (iteration %d)" % it
+    check(y1, L.linear_ref(a, w, b, res=res), dtype, "gemm split%d in-kernel tile%d" % (split, tile))
+    name = ops._kname(ops._native.load(), _desc_for(ops, a, w, tile, split))
+    assert name[1] >= 2 and name[2], "the in-launch form was not taken: %s" % (name,)
+
+
+def _desc_for(ops, a, w, tile, split):
+    d = ops.GemmDesc()
+    d.a, d.w, d.out = a.data_ptr(), w.data_ptr(), a.data_ptr()
+    d.rows, d.n, d.k, d.k1 = a.shape[0], w.shape[0], a.shape[1], a.shape[1]
+    d.lda, d.ldc, d.alpha = a.stride(0), w.shape[0], 1.0
+    d.dtype = ops.DD_F16 if a.dtype == torch.float16 else ops.DD_BF16
+    d.tile, d.split_k, d.splitk_inkernel = tile, split, 1
+    return d
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile,case,split", [(31, (12, 4, 7, 1280, 1280), 5), (31, (12, 7, 13, 640, 1280), 2),
+                                             (33, (12, 7, 13, 1280, 1280), 4), (31, (3, 14, 25, 640, 640), 2), (37, (7, 7, 13, 192, 64), 3),
+                                             (31, (5, 4, 7, 2560, 1280), 8), (39, (3, 28, 50, 320, 320), 5),
+                                             (12, (12, 7, 13, 640, 1280), 3)], ids=lambda v: str(v))
+def test_conv_split_k_inkernel_bitwise(ops, dtype, tile, case, split):
+    """The direct small-image conv, its band form and the implicit-GEMM conv with the in-launch reduction, with the
+    ResnetBlock2D epilogue (bias + time vector + residual) run by the last-arriving slice."""
+    m, h, w_, cin, cout = case
+    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
+    wp = L.pack_conv_weight(w)
+    b = rnd((cout,), dtype, 3)
+    for it in range(4):
+        x = rnd((m * h * w_, cin), dtype, 30 + it)
+        temb = rnd((m, cout), dtype, 40 + it)
+        res = rnd((m * h * w_, cout), dtype, 50 + it)
+        y2 = ops.conv3x3(x, wp, b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split, splitk_inkernel=0)
+        y1 = ops.conv3x3(x, wp, b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split, splitk_inkernel=1)
+        assert torch.equal(y1, y2), "conv in-launch reduction differs (iteration %d)" % it
+    ref = L.conv3x3_ref(x, w, b, m, h, w_) + temb.float().cpu().repeat_interleave(h * w_, 0) + res.float().cpu()
+    check(y1, ref, dtype, "conv tile%d split%d in-kernel %s" % (tile, split, case))
+
+
+def test_split_k_inkernel_under_load_and_streams(ops):
+    """Pitfall 3 of the guide's hand-off section: a test on an idle chip with cold lines can pass while the kernel
+    is stale.  Here two streams run in-launch split-K GEMMs of different shapes concurrently (each stream has its
+    own workspace), 40 launches each with fresh inputs, while a third stream streams through a 1 GiB buffer; every
+    result is compared bitwise with the two-launch form computed afterwards."""
+    dtype = torch.float16
+    shapes = [(1092, 1280, 1280, 13, 4), (336, 1280, 5120, 15, 8)]
+    ws = [rnd((n, k), dtype, 2 + i, k ** -0.5) for i, (_, n, k, _, _) in enumerate(shapes)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    outs = [[], []]
+    ins = [[rnd((rows, k), dtype, 100 * i + it) for it in range(40)] for i, (rows, _, k, _, _) in enumerate(shapes)]
+    torch.cuda.synchronize()
+    for it in range(40):
+        with torch.cuda.stream(streams[2]):
+            big.add_(1)
+        for i, (rows, n, k, tile, split) in enumerate(shapes):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(ops.gemm(ins[i][it], ws[i], tile=tile, split_k=split, splitk_inkernel=1))
+    torch.cuda.synchronize()
+    for i, (rows, n, k, tile, split) in enumerate(shapes):
+        for it in range(40):
+            y2 = ops.gemm(ins[i][it], ws[i], tile=tile, split_k=split, splitk_inkernel=0)
+            assert torch.equal(outs[i][it], y2), "shape %d launch %d" % (i, it)
