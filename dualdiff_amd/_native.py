@@ -52,6 +52,7 @@ class AttnDesc(Structure):
         ("accumulate", c_int32), ("dtype", c_int32), ("variant", c_int32),
         ("q_head_stride", c_int64), ("k_head_stride", c_int64), ("v_head_stride", c_int64),
         ("q_prescaled", c_int32),
+        ("kv_batch_map2", c_void_p),
     ]
 
 

@@ -39,6 +39,7 @@ struct AttnParams {
   int nqb;             // q-blocks per (batch, head), filled by the launcher
   int64_t qhs, khs, vhs;   // head strides (elements)
   int prescaled;           // q carries scale * log2(e)
+  const int32_t* kv_map2;  // second K/V batch map: O = Attn(q, kv[map]) + Attn(q, kv[map2]) in ONE launch (v5 family)
 };
 
 
@@ -313,7 +314,7 @@ void dd_attn_kernel(const AttnParams p) {
 // PRE: q arrives pre-multiplied by scale * log2(e) (dd_gemm_desc.hm_scale), so the scores leave the QK^T
 // MFMA in log2 units — and with the running max negated in the MFMA's C operand they leave it already
 // shifted: p = exp2(acc), no per-score FMA (16 of the ~70 VALU instructions per 32-key chunk).
-template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE, bool PRE>
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE, bool PRE, bool PAIR = false>
 __global__ __launch_bounds__(256, WPE)
 void dd_attn5_kernel(const AttnParams p) {
   using V8 = typename dd_vec<T>::v8;
@@ -350,17 +351,17 @@ void dd_attn5_kernel(const AttnParams p) {
   const int qb = item - bh * nqb;
   const int b = bh / p.heads;
   const int h = bh - b * p.heads;
-  const int kb = p.kv_map ? p.kv_map[b] : b;
   const int q0 = (qb * 4 + wave) * (QT * 16);
 
   const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * p.qhs;
-  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * p.khs;
-  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * p.vhs;
   const uint32_t k_row_bytes = (uint32_t)p.ldk * sizeof(T), v_row_bytes = (uint32_t)p.ldv * sizeof(T);
-  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(kbase), 0, (uint32_t)(p.lk - 1) * k_row_bytes + D * sizeof(T), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(vbase), 0, (uint32_t)(p.lk - 1) * v_row_bytes + D * sizeof(T), 0x00020000);
+  // Neighbour-view PAIR (p.kv_map2, reference blocks.py:203-217: out = Attn(q, kv_left) + Attn(q, kv_right)): two passes
+  // of the same loop over two K/V instances with their own softmax state; the first pass's normalised output waits in
+  // LDS (fp32, behind the K/V tiles) and the sum is rounded ONCE — one launch, no read-modify-write of O.
+  // (PAIR is a template parameter: the single-attention instantiations keep their register allocation — with a run-time
+  // pass loop the 48-rows-per-wave d = 40 kernel went from 162 VGPRs / no spill to 168 / 6 spilled)
+  constexpr int npass = PAIR ? 2 : 1;
+  f32x4* stash = reinterpret_cast<f32x4*>(smem + (size_t)NBUF * TILE_ELEMS * sizeof(T));
 
   // per-lane chunk tables: global byte offsets inside a tile and LDS element offsets
   uint32_t gk[PER], gv[PER];
@@ -406,16 +407,39 @@ void dd_attn5_kernel(const AttnParams p) {
   }
 
   f32x4 oacc[DVT][QT];
+  float m_run[QT], l_run[QT];
+  f32x4 cinit[QT];                       // PRE: -m_run broadcast, the C operand of the first QK^T MFMA
+  const int ntiles = (p.lk + KV_TILE - 1) / KV_TILE;
+
+  for (int pass = 0; pass < npass; ++pass) {
+  const int kb = pass ? p.kv_map2[b] : (p.kv_map ? p.kv_map[b] : b);
+  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * p.khs;
+  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * p.vhs;
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(kbase), 0, (uint32_t)(p.lk - 1) * k_row_bytes + D * sizeof(T), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(vbase), 0, (uint32_t)(p.lk - 1) * v_row_bytes + D * sizeof(T), 0x00020000);
 #pragma unroll
   for (int i = 0; i < DVT; ++i)
 #pragma unroll
     for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[QT], l_run[QT];
 #pragma unroll
   for (int j = 0; j < QT; ++j) { m_run[j] = PRE ? 0.f : -1e30f; l_run[j] = 0.f; }
-  f32x4 cinit[QT];                       // PRE: -m_run broadcast, the C operand of the first QK^T MFMA
 #pragma unroll
   for (int j = 0; j < QT; ++j) cinit[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (pass) {
+    __syncthreads();                     // every wave is done with the first pass's last tile
+    if (ONES && (p.lk % KV_TILE) != 0) { // ... whose ragged rows lost their ones entry: restore the column
+      const T one_t = (T)1.0f;
+      unsigned short one_u16;
+      __builtin_memcpy(&one_u16, &one_t, 2);
+      const u32x4 ones = {(unsigned)one_u16, 0u, 0u, 0u};
+      for (int idx = tid; idx < NBUF * KV_TILE; idx += 256) {
+        const int buf = idx / KV_TILE, row = idx - buf * KV_TILE;
+        dd_st16(lds + buf * TILE_ELEMS + KV_TILE * KSTR + row * VSTR + DCH * 8, ones);
+      }
+    }
+  }
 
   u32x4 kreg[PER], vreg[PER];
   auto load_kv = [&](int tile0) {
@@ -440,7 +464,6 @@ void dd_attn5_kernel(const AttnParams p) {
       }
   };
 
-  const int ntiles = (p.lk + KV_TILE - 1) / KV_TILE;
   load_kv(0);
 
   for (int it = 0; it < ntiles; ++it) {
@@ -577,7 +600,7 @@ void dd_attn5_kernel(const AttnParams p) {
     }
   }
 
-  T* obase = reinterpret_cast<T*>(p.o) + (int64_t)b * p.obs + h * D;
+  // normalise this pass (row sums: the ones column of V, or l_run)
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
     float l;
@@ -589,6 +612,32 @@ void dd_attn5_kernel(const AttnParams p) {
       l += __shfl_xor(l, 32, 64);
     }
     const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      oacc[dt][j][0] *= inv; oacc[dt][j][1] *= inv; oacc[dt][j][2] *= inv; oacc[dt][j][3] *= inv;
+    }
+  }
+  if (npass == 2) {
+    if (pass == 0) {                     // park the first neighbour's result (thread-private slots: no barrier)
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) stash[(dt * QT + j) * 256 + tid] = oacc[dt][j];
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+          const f32x4 o0 = stash[(dt * QT + j) * 256 + tid];
+          oacc[dt][j][0] += o0[0]; oacc[dt][j][1] += o0[1]; oacc[dt][j][2] += o0[2]; oacc[dt][j][3] += o0[3];
+        }
+    }
+  }
+  }   // pass
+
+  T* obase = reinterpret_cast<T*>(p.o) + (int64_t)b * p.obs + h * D;
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
     const int qrow = q0 + j * 16 + c;
     if (qrow >= p.lq) continue;
 #pragma unroll
@@ -596,7 +645,7 @@ void dd_attn5_kernel(const AttnParams p) {
       const int d0 = dt * 16 + g * 4;
       if (d0 >= D) continue;
       T* dst = obase + (int64_t)qrow * p.ldo + d0;
-      float o4[4] = {oacc[dt][j][0] * inv, oacc[dt][j][1] * inv, oacc[dt][j][2] * inv, oacc[dt][j][3] * inv};
+      float o4[4] = {oacc[dt][j][0], oacc[dt][j][1], oacc[dt][j][2], oacc[dt][j][3]};
       if (p.accumulate) {
         V4 prev = *reinterpret_cast<const V4*>(dst);
 #pragma unroll
@@ -610,7 +659,7 @@ void dd_attn5_kernel(const AttnParams p) {
   }
 }
 
-template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE, bool PRE>
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE, bool PRE, bool PAIR = false>
 int launch_attn5p(const AttnParams& p, hipStream_t s) {
   constexpr int DQ = (D + 31) / 32 * 32;
   constexpr int DVT = (D + 15) / 16;
@@ -619,10 +668,13 @@ int launch_attn5p(const AttnParams& p, hipStream_t s) {
   AttnParams pp = p;
   pp.nqb = (p.lq + qblk - 1) / qblk;
   dim3 grid(pp.nqb * p.batch * p.heads);
-  auto kern = dd_attn5_kernel<T, D, QT, KV_TILE, NBUF, WPE, PRE>;
+  auto kern = dd_attn5_kernel<T, D, QT, KV_TILE, NBUF, WPE, PRE, PAIR>;
+  constexpr size_t stash = PAIR ? (size_t)DVT * QT * 256 * sizeof(f32x4) : 0;   // neighbour pair: the first pass's output
+  static_assert(smem + stash <= 160 * 1024, "LDS");
+  if (PAIR != (p.kv_map2 != nullptr)) return DD_ERR_UNSUPPORTED;
   static std::atomic<uint64_t> attr_done{0};       // per instantiation, one bit per device
-  dd_ensure_dyn_lds((const void*)kern, smem, attr_done);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, pp);
+  dd_ensure_dyn_lds((const void*)kern, smem + stash, attr_done);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem + stash, s, pp);
   return dd_check_launch();
 }
 
@@ -630,6 +682,16 @@ template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE = 1>
 int launch_attn5(const AttnParams& p, hipStream_t s) {
   if (p.prescaled) return launch_attn5p<T, D, QT, KV_TILE, NBUF, WPE, true>(p, s);
   return launch_attn5p<T, D, QT, KV_TILE, NBUF, WPE, false>(p, s);
+}
+
+// the DEFAULT configurations also exist as neighbour-PAIR kernels (dd_attn_desc.kv_batch_map2)
+template <typename T, int D, int QT, int KV_TILE, int NBUF, int WPE = 1>
+int launch_attn5d(const AttnParams& p, hipStream_t s) {
+  if (p.kv_map2) {
+    if (p.prescaled) return launch_attn5p<T, D, QT, KV_TILE, NBUF, WPE, true, true>(p, s);
+    return launch_attn5p<T, D, QT, KV_TILE, NBUF, WPE, false, true>(p, s);
+  }
+  return launch_attn5<T, D, QT, KV_TILE, NBUF, WPE>(p, s);
 }
 
 template <typename T, int D, int QT, bool TR, int KV_TILE>
@@ -651,6 +713,7 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
   // 128-key tiles (half the barriers) for long key sequences at the small head dims
   const long blocks128 = (long)((p.lq + 127) / 128) * p.batch * p.heads;
   const bool qt2 = p.lq >= 256 && blocks128 >= 512;
+  if (p.kv_map2 && variant != 0) return DD_ERR_UNSUPPORTED;          // the pair exists for the default kernels only
   if (variant == 1) {
     return qt2 ? launch_attn<T, D, 2, false, 64>(p, s) : launch_attn<T, D, 1, false, 64>(p, s);
   }
@@ -668,6 +731,7 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
   const bool v5_ok = (int64_t)p.lk * p.ldk * (int64_t)sizeof(T) < (1ll << 31) &&
                      (int64_t)p.lk * p.ldv * (int64_t)sizeof(T) < (1ll << 31);
   if (variant >= 5 && variant <= 12 && !v5_ok) return DD_ERR_UNSUPPORTED;
+  if (p.kv_map2 && !v5_ok) return DD_ERR_UNSUPPORTED;
   if (variant == 9) { if constexpr (D == 40) return launch_attn5<T, D, 2, 64, 1, 4>(p, s); }
   if (variant == 10) { if constexpr (D == 40) return launch_attn5<T, D, 2, 128, 1, 4>(p, s); }
   if (variant == 11) { if constexpr (D == 40) return launch_attn5<T, D, 3, 64, 1, 3>(p, s); }
@@ -690,16 +754,16 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
         auto waste = [](double g) { double c = (double)(long)g; if (c < g) c += 1.0; return c / g; };
         if (waste(g3) < waste(g2) - 0.05)
           // (the prescaled-q variant of the 128-key tile spills at 48 rows per wave: 64-key tiles there)
-          return p.lk >= 512 && !p.prescaled ? launch_attn5<T, D, 3, 128, 1, 3>(p, s)
-                                             : launch_attn5<T, D, 3, 64, 1, 3>(p, s);
-        return launch_attn5<T, D, 2, 64, 1>(p, s);
+          return p.lk >= 512 && !p.prescaled ? launch_attn5d<T, D, 3, 128, 1, 3>(p, s)
+                                             : launch_attn5d<T, D, 3, 64, 1, 3>(p, s);
+        return launch_attn5d<T, D, 2, 64, 1>(p, s);
       }
-      return launch_attn5<T, D, 1, 64, 1>(p, s);
+      return launch_attn5d<T, D, 1, 64, 1>(p, s);
     } else if constexpr (D == 80) {
-      if (qt2) return p.lk >= 512 ? launch_attn5<T, D, 2, 128, 1>(p, s) : launch_attn5<T, D, 2, 64, 1>(p, s);
-      return launch_attn5<T, D, 1, 64, 1>(p, s);
+      if (qt2) return p.lk >= 512 ? launch_attn5d<T, D, 2, 128, 1>(p, s) : launch_attn5d<T, D, 2, 64, 1>(p, s);
+      return launch_attn5d<T, D, 1, 64, 1>(p, s);
     } else {
-      return qt2 ? launch_attn5<T, D, 2, 64, 1>(p, s) : launch_attn5<T, D, 1, 64, 1>(p, s);
+      return qt2 ? launch_attn5d<T, D, 2, 64, 1>(p, s) : launch_attn5d<T, D, 1, 64, 1>(p, s);
     }
   }
   if constexpr (D <= 80) {
@@ -738,6 +802,8 @@ extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
   p.batch = d->batch; p.heads = d->heads; p.lq = d->lq; p.lk = d->lk;
   p.scale_log2 = d->scale * 1.44269504088896340736f;
   p.kv_map = d->kv_batch_map; p.accumulate = d->accumulate;
+  p.kv_map2 = d->kv_batch_map2;
+  if (p.kv_map2 && !p.kv_map) return DD_ERR_BAD_ARG;
   p.qhs = d->q_head_stride ? d->q_head_stride : d->head_dim;
   p.khs = d->k_head_stride ? d->k_head_stride : d->head_dim;
   p.vhs = d->v_head_stride ? d->v_head_stride : d->head_dim;

@@ -24,6 +24,22 @@ def _ensure_kv_is_int(view_pair):
     return {int(k): [int(x) for x in v] for k, v in view_pair.items()}
 
 
+# Both neighbours of a view in ONE attention launch (dd_attn_desc.kv_batch_map2): two softmax passes inside the kernel,
+# summed in fp32, instead of two launches of which the second reads O back to accumulate.  DD_ATTN4_PAIR=0: two launches.
+ATTN4_PAIR = __import__("os").environ.get("DD_ATTN4_PAIR", "1") != "0"
+
+
+def _neighbour_sum(q, k, v, batch, l, heads, dim_head, scale, maps, prescaled):
+    """sum_j Attn(q, kv[maps[j]]) (blocks.py:203-217): pairs of neighbours per launch, a single one accumulates."""
+    o, j = None, 0
+    while j < len(maps):
+        pair = ATTN4_PAIR and j + 1 < len(maps)
+        o = O.attention(q, k, v, batch, l, l, heads, dim_head, scale, kv_batch_map=maps[j],
+                        kv_batch_map2=maps[j + 1] if pair else None, out=o, accumulate=j > 0, q_prescaled=prescaled)
+        j += 2 if pair else 1
+    return o
+
+
 class GatedConnector(nn.Module):
     """tanh(alpha) * x with a zero-initialised per-channel alpha (blocks.py:24-32); on the HIP path the gate is
     folded into the out-projection weights like the Linear connector."""
@@ -131,10 +147,7 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
         flat = kv.reshape(sh.plan.n_slots * nbat, 2 * hd, l, d)
         k4, v4 = flat[:, :hd], flat[:, hd:]
         maps = sh.maps(nbat, h.device)
-        o = None
-        for j, mp in enumerate(maps):
-            o = O.attention(qkv[:hd], k4, v4, batch, l, l, hd, d, a.scale, kv_batch_map=mp, out=o,
-                            accumulate=j > 0, q_prescaled=True)
+        o = _neighbour_sum(qkv[:hd], k4, v4, batch, l, hd, d, a.scale, maps, True)
         return o, len(maps)
 
     def _cross_view(self, h, batch, l):
@@ -179,10 +192,7 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             q, k, v = ((qkv[:a.heads], qkv[a.heads:2 * a.heads], qkv[2 * a.heads:]) if hm
                        else (qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]))
             maps = self.neighbour_maps(batch, h.device)
-            o = None
-            for j, mp in enumerate(maps):
-                o = O.attention(q, k, v, batch, l, l, a.heads, a.dim_head, a.scale, kv_batch_map=mp, out=o,
-                                accumulate=j > 0, q_prescaled=hm)
+            o = _neighbour_sum(q, k, v, batch, l, a.heads, a.dim_head, a.scale, maps, hm)
             nb = len(maps)
         # connector(to_out(...)) as one GEMM with the residual add (folded weights, see _folded_out)
         w, b = self._folded_out(nb)

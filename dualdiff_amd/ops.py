@@ -664,7 +664,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_map=None,
               out=None, accumulate=False, variant=0, q_prescaled=False, seq_strides=None,
-              out_seq_strides=None):
+              out_seq_strides=None, kv_batch_map2=None):
     """softmax(scale * q k^T) v per (batch, head).
 
     q / k / v may also be HEAD-MAJOR 3-D tensors (heads, rows, head_dim) — slices of a
@@ -672,14 +672,17 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
 
     q: (batch*lq, >= heads*head_dim) row-strided view; k, v: (kv_batches*lk, ...) likewise, so
     slices of a fused QKV projection can be passed without copies.  kv_batch_map (int32 device
-    tensor [batch]) redirects batch b to K/V of another batch (neighbour views).
+    tensor [batch]) redirects batch b to K/V of another batch (neighbour views); with kv_batch_map2 as well the
+    result is Attn(q, kv[map]) + Attn(q, kv[map2]) — the neighbour-view PAIR of attn4 in one launch.
 
     seq_strides = (row_stride, batch_stride) in elements for q, k, v (row-major 2-D views with the same row
     pitch), out_seq_strides likewise for `out` (default: the same): the sequence runs over rows `row_stride`
     apart and consecutive batches start `batch_stride` apart — attention ALONG ANOTHER AXIS of a (frames, tokens, C) activation without a transpose
     (temporal attention: row_stride = tokens_per_frame * C, batch_stride = C)."""
     lib = _native.load()
-    _need_gpu(q, k, v, out, kv_batch_map)
+    _need_gpu(q, k, v, out, kv_batch_map, kv_batch_map2)
+    if kv_batch_map2 is not None and (kv_batch_map is None or seq_strides is not None):
+        raise ValueError("kv_batch_map2 needs kv_batch_map and no seq_strides")
     d = AttnDesc()
 
     def operand(t, l):
@@ -718,6 +721,8 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     d.batch, d.heads, d.head_dim, d.lq, d.lk = batch, heads, head_dim, lq, lk
     d.scale = float(scale) if scale is not None else head_dim ** -0.5
     d.kv_batch_map = kv_batch_map.data_ptr() if kv_batch_map is not None else None
+    d.kv_batch_map2 = kv_batch_map2.data_ptr() if kv_batch_map2 is not None else None
+    npair = 2 if kv_batch_map2 is not None else 1
     d.accumulate = int(accumulate)
     d.dtype = _dt(q)
     d.variant = variant
@@ -735,8 +740,8 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
         e0 = _TIMER.start()
         _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
         _TIMER.stop(e0, "dd_attn5_kernel<%s,D%d>" % ("f16" if d.dtype == DD_F16 else "bf16", head_dim),
-                    4.0 * batch * heads * lq * lk * head_dim,
-                    2.0 * heads * head_dim * batch * (2 * lq + 2 * lk))
+                    4.0 * batch * heads * lq * lk * head_dim * npair,
+                    2.0 * heads * head_dim * batch * (2 * lq + 2 * lk * npair))
         return out
     _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
     return out

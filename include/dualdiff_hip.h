@@ -236,6 +236,11 @@ typedef struct dd_attn_desc {
    * out_headmajor_d) passes ld = head_dim, batch stride = l * head_dim, head stride = rows * head_dim. */
   int64_t q_head_stride, k_head_stride, v_head_stride;
   int32_t q_prescaled;                /* 1: q already carries scale * log2(e); `scale` is ignored */
+  /* Neighbour PAIR in one launch (networks/blocks.py:203-217, attn4 with neighboring_attn_type="add"):
+   *   O[b] (op)= Attn(Q[b], K/V[kv_batch_map[b]]) + Attn(Q[b], K/V[kv_batch_map2[b]])
+   * — two softmaxes with their own normalisation, summed in fp32 and rounded once.  Needs kv_batch_map and the default
+   * variant (0); NULL = single attention. */
+  const int32_t* kv_batch_map2;
 } dd_attn_desc;
 
 int dd_attention(const dd_attn_desc* d, dd_stream_t stream);

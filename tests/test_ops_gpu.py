@@ -1033,3 +1033,59 @@ def test_split_k_inkernel_under_load_and_streams(ops):
         for it in range(40):
             y2 = ops.gemm(ins[i][it], ws[i], tile=tile, split_k=split, splitk_inkernel=0)
             assert torch.equal(outs[i][it], y2), "shape %d launch %d" % (i, it)
+
+
+# ------------------------------------------------------------------ neighbour PAIR in one attention launch ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("prescaled", [False, True])
+@pytest.mark.parametrize("b,l,h,d", [(12, 1400, 8, 40), (6, 350, 8, 80), (12, 91, 8, 160), (6, 28, 8, 160), (6, 130, 2, 40),
+                                     (6, 65, 8, 80)])
+def test_attention_neighbour_pair_one_launch(ops, dtype, prescaled, b, l, h, d):
+    """dd_attn_desc.kv_batch_map2 (round 3): Attn(q, kv[left]) + Attn(q, kv[right]) in ONE launch — two softmax passes
+    with their own state, summed in fp32 and rounded once — against the oracle's sum and against the two-launch
+    accumulate form it replaces (which rounds twice), on head-major planes as the model passes them."""
+    c = h * d
+    scale = d ** -0.5
+    qkv = rnd((b * l, 3 * c), dtype, 1)
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    n = 6
+    left = torch.tensor([(i // n) * n + (i % n + n - 1) % n for i in range(b)], dtype=torch.int32, device="cuda")
+    right = torch.tensor([(i // n) * n + (i % n + 1) % n for i in range(b)], dtype=torch.int32, device="cuda")
+    ref = (L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=left)
+           + L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=right))
+    if prescaled:       # head-major planes, Q carrying scale * log2(e) (what the projection epilogue writes)
+        def planes(t, s=1.0):
+            return (t.float() * s).to(dtype).reshape(b * l, h, d).permute(1, 0, 2).contiguous()
+        qh, kh, vh = planes(q, scale * 1.4426950408889634), planes(k), planes(v)
+        one = ops.attention(qh, kh, vh, b, l, l, h, d, kv_batch_map=left, kv_batch_map2=right, q_prescaled=True)
+        two = ops.attention(qh, kh, vh, b, l, l, h, d, kv_batch_map=left, q_prescaled=True)
+        ops.attention(qh, kh, vh, b, l, l, h, d, kv_batch_map=right, out=two, accumulate=True, q_prescaled=True)
+    else:
+        one = ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left, kv_batch_map2=right)
+        two = ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left)
+        ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=right, out=two, accumulate=True)
+    if prescaled:
+        # Q was rounded AFTER the scale went in (as the projection epilogue does), so the oracle on the unscaled
+        # operands is not the yardstick here: the two-launch form on the SAME planes is (it rounds twice -> 2 ulp)
+        check(one, two.float().cpu(), dtype, "neighbour pair (head-major, prescaled) vs two launches b=%d l=%d d=%d" % (b, l, d), 3.0)
+    else:
+        check(one, ref, dtype, "neighbour pair one launch b=%d l=%d d=%d" % (b, l, d), 4.0)
+        # one rounding instead of two: never worse than the two-launch form against the oracle
+        e1 = (one.float().cpu() - ref).abs().max().item()
+        e2 = (two.float().cpu() - ref).abs().max().item()
+        assert e1 <= e2 * 1.05 + 1e-6, (e1, e2)
+    # and a third neighbour still accumulates on top (odd neighbour counts)
+    three = ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left, kv_batch_map2=right)
+    ops.attention(q, k, v, b, l, l, h, d, kv_batch_map=left, out=three, accumulate=True)
+    ref3 = ref + L.attention_ref(q, k, v, b, l, l, h, d, kv_batch_map=left)
+    if not prescaled:
+        check(three, ref3, dtype, "pair + accumulate", 6.0)
+
+
+def test_attention_pair_rejects(ops):
+    q = rnd((6 * 64, 320), torch.float16, 1)
+    mp = torch.arange(6, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map2=mp)                    # needs kv_batch_map
+    with pytest.raises(RuntimeError):
+        ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map=mp, kv_batch_map2=mp, variant=7)   # default kernels only
