@@ -56,6 +56,19 @@ class AttnDesc(Structure):
     ]
 
 
+class XAttnDesc(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64), ("res", c_void_p), ("ldres", c_int64),
+        ("wq", c_void_p), ("wo", c_void_p), ("bo", c_void_p),
+        ("k", c_void_p), ("v", c_void_p), ("ldk", c_int64), ("ldv", c_int64),
+        ("k_inst_stride", c_int64), ("k_head_stride", c_int64), ("v_inst_stride", c_int64), ("v_head_stride", c_int64),
+        ("out", c_void_p), ("ldo", c_int64),
+        ("instances", c_int32), ("rows_per_inst", c_int32), ("lk", c_int32),
+        ("channels", c_int32), ("heads", c_int32), ("scale", c_float), ("dtype", c_int32),
+        ("ln_out", c_void_p), ("ld_ln_out", c_int64), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+    ]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "dd_abi_version": (c_int32, []),
@@ -77,6 +90,8 @@ SIGNATURES = {
     "dd_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_scale": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p]),
     "dd_probe_spin": (c_int32, [c_void_p, c_uint32, c_void_p]),
+    "dd_xattn320": (c_int32, [POINTER(XAttnDesc), c_void_p]),
+    "dd_xattn_pack_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "dd_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -270,6 +270,11 @@ def ln_direct_ok(norm, k, n, kw=None):
     return O.rowpanel_ok(k, n)
 
 
+# Fused cross-attention kernel of the 320-channel level (dd_xattn320: to_q -> SDPA over <= 128 context keys -> to_out +
+# residual + next LayerNorm in one launch; SFA and attn2 of the 28x50 blocks).  DD_XATTN_FUSED=0: the three launches.
+XATTN_FUSED = __import__("os").environ.get("DD_XATTN_FUSED", "1") != "0"
+
+
 # Head-major Q / K / V planes + softmax scale folded into Q by the projection epilogue (dd_gemm_desc.
 # out_headmajor_d, dd_attn_desc.q_prescaled).  DD_ATTN_HEAD_MAJOR=0 restores the fused row-major layout.
 HEAD_MAJOR = __import__("os").environ.get("DD_ATTN_HEAD_MAJOR", "1") != "0"
@@ -515,9 +520,6 @@ class Attention(_Cached):
 
     def run_cross(self, x2d, batch, lq, ctx2d, lk, res=None, kv=None, norm=None, ln_stats=False, ln_next=None):
         c = self.inner_dim
-        q_hm = HEAD_MAJOR and self.to_q.bias is None
-        kw = {"head_major": self._hm(self.heads)} if q_hm else {}
-        q = self.to_q.run(x2d, **kw) if norm is None else self.to_q.run_ln(x2d, norm, **kw)
         pre = self.__dict__.pop("_kv_prefetched", None)
         if kv is None and pre is not None and pre[0] is ctx2d:
             kv, side = pre[1], pre[2]                # projected ahead of time (bank GEMM, or a side stream)
@@ -527,6 +529,20 @@ class Attention(_Cached):
                     kv.record_stream(torch.cuda.current_stream())
         if kv is None:
             kv = self.project_kv(ctx2d)
+        if XATTN_FUSED and O.xattn320_ok(c, self.heads, lk) and self.to_q.in_features == c and self.to_q.bias is None \
+                and not self.fp8 and not ln_stats and LN_FOLD == "0" and not LN_DIRECT:
+            # 28x50 level: q-projection, attention over the <= 128 context keys and out-projection + residual in ONE
+            # launch (csrc/xattn.hip); it owns whole rows, so it also emits the next sub-layer's LayerNorm
+            xn = x2d if norm is None else norm.run(x2d)
+            lno = (ln_next.weight, ln_next.bias, ln_next.eps) if LN_PRODUCER and isinstance(ln_next, LayerNorm) else None
+            out = O.xattn320(xn, self.to_q.w2d, self.to_out[0].w2d, self.to_out[0].bias, kv[:, :c], kv[:, c:], batch, lq,
+                             lk, self.scale, res=res, ln_out=lno)
+            if lno is not None:
+                out._ln_cache = (ln_next, out._ln_out)
+            return out
+        q_hm = HEAD_MAJOR and self.to_q.bias is None
+        kw = {"head_major": self._hm(self.heads)} if q_hm else {}
+        q = self.to_q.run(x2d, **kw) if norm is None else self.to_q.run_ln(x2d, norm, **kw)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale,
                         q_prescaled=q_hm)
         return self.to_out[0].run(o, res=res, ln_stats=ln_stats, ln_next=ln_next)

@@ -53,8 +53,16 @@ class txt_con_XFormersAttn(_SFABase):
         if "_pk_kv" not in self.__dict__ or self.__dict__["_pk_kv"].dtype != x.dtype \
                 or self.__dict__["_pk_kv"].device != x.device:
             self.__dict__["_pk_kv"] = torch.cat([self.to_k.weight.detach(), self.to_v.weight.detach()], 0).contiguous()
-        q = self.to_q.run(x)
+        from . import layers
+        if layers.XATTN_FUSED and O.xattn320_ok(c, self.heads, lk) and x.shape[1] == c:
+            # to_q -> attention over the text keys -> to_out + bias + residual in ONE launch (csrc/xattn.hip); K | V of
+            # the text tokens as one contiguous [keys][40] block per head (the form the kernel streams fastest)
+            hd = self.heads
+            kvh = O.gemm(e2d, self.__dict__["_pk_kv"], head_major=(c // hd, 0, 1.0))        # (16, b * lk, 40)
+            return O.xattn320(x, self.to_q.w2d, self.to_out[0].w2d, self.to_out[0].bias, kvh[:hd], kvh[hd:], b, lq, lk,
+                              self.scale, res=x if self.residual_connection else None)
         kv = O.gemm(e2d, self.__dict__["_pk_kv"])
+        q = self.to_q.run(x)
         o = O.attention(q, kv[:, :c], kv[:, c:], b, lq, lk, self.heads, c // self.heads, self.scale)
         return self.to_out[0].run(o, res=x if self.residual_connection else None)
 

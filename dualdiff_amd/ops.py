@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _native
-from ._native import DD_BF16, DD_EPI_GEGLU, DD_EPI_NONE, DD_EPI_SILU, DD_F16, AttnDesc, GemmDesc
+from ._native import DD_BF16, DD_EPI_GEGLU, DD_EPI_NONE, DD_EPI_SILU, DD_F16, AttnDesc, GemmDesc, XAttnDesc
 
 _WS = {}
 _WS_MIN_BYTES = 64 << 20
@@ -744,6 +744,99 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
                     2.0 * heads * head_dim * batch * (2 * lq + 2 * lk * npair))
         return out
     _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
+    return out
+
+
+_ZERO_BIAS = {}
+
+
+def xattn320_ok(c, heads, lk):
+    """Shapes the fused cross-attention kernel covers (dd_xattn320): the 320-channel level, 8 heads, <= 128 keys."""
+    return int(c) == 320 and int(heads) == 8 and 0 < int(lk) <= 128
+
+
+_XPACK = {}
+
+
+def xattn_packed_weight(w):
+    """[320, 320] Linear weight -> the K-step-major, pre-swizzled copy dd_xattn320 streams by linear LDS-DMA
+    (dd_xattn_pack_weight).  Cached per weight tensor (storage pointer + version counter)."""
+    key = (w.data_ptr(), w._version, w.dtype, str(w.device))
+    hit = _XPACK.get(id(w))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if tuple(w.shape) != (320, 320) or not w.is_contiguous():
+        raise ValueError("xattn320 weights must be contiguous (320, 320)")
+    lib = _native.load()
+    packed = torch.empty(320 * 320, dtype=w.dtype, device=w.device)
+    _native.check(lib.dd_xattn_pack_weight(_ptr(w), _ptr(packed), _dt(w), _stream()), "xattn_pack_weight")
+    if len(_XPACK) > 256:
+        _XPACK.clear()
+    _XPACK[id(w)] = (key, packed, w)          # keeps `w` alive so that id(w) cannot be recycled under the entry
+    return packed
+
+
+def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=None, ln_out=None, out=None):
+    """Fused q-projection -> attention over the lk context keys of each view-instance -> out-projection + bias +
+    residual, one launch (include/dualdiff_hip.h: dd_xattn320).  x: (instances * rows_per_inst, 320); k / v: either
+    (instances * lk, >= 320) row-strided 2-D views (column slices of a wider projection) or HEAD-MAJOR 3-D tensors
+    (8, instances * lk, 40) — slices of a `gemm(..., head_major=(40, 0, 1.0))` result, the form the kernel streams
+    fastest; wq / wo: the (320, 320) Linear weights (packed and cached here); ln_out = (gamma, beta, eps):
+    LayerNorm(out) comes back as `out._ln_out`."""
+    lib = _native.load()
+    _need_gpu(x, wq, wo, bo, k, v, res, out)
+    x = _rows2d(x)
+    rows = instances * rows_per_inst
+    if x.shape != (rows, 320):
+        raise ValueError("xattn320: x must be (instances * rows_per_inst, 320)")
+
+    def kv_operand(t):
+        if t.dim() == 3:                      # head-major planes
+            if t.shape[0] != 8 or t.shape[1] != instances * lk or t.shape[2] != 40 or t.stride(2) != 1 or t.stride(1) != 40:
+                raise ValueError("head-major K / V must be (8, instances * lk, 40) with contiguous planes")
+            return t.data_ptr(), 40, lk * 40, t.stride(0)
+        t = _rows2d(t)
+        if t.shape[0] != instances * lk or t.shape[1] < 320:
+            raise ValueError("row-major K / V must be (instances * lk, >= 320)")
+        return t.data_ptr(), t.stride(0), lk * t.stride(0), 40
+    if out is None:
+        out = torch.empty((rows, 320), dtype=x.dtype, device=x.device)
+    else:
+        _forget_derived(out)
+    out = _rows2d(out)
+    wqp, wop = xattn_packed_weight(wq), xattn_packed_weight(wo)
+    d = XAttnDesc()
+    d.x, d.ldx = x.data_ptr(), x.stride(0)
+    if res is not None:
+        res = _rows2d(res)
+        d.res, d.ldres = res.data_ptr(), res.stride(0)
+    d.wq, d.wo = wqp.data_ptr(), wop.data_ptr()
+    if bo is None:                      # the kernel loads the bias unconditionally (a conditional load would be waited for in place)
+        key = (x.dtype, x.device)
+        if key not in _ZERO_BIAS:
+            _ZERO_BIAS[key] = torch.zeros(320, dtype=x.dtype, device=x.device)
+        bo = _ZERO_BIAS[key]
+    d.bo = bo.data_ptr()
+    d.k, d.ldk, d.k_inst_stride, d.k_head_stride = kv_operand(k)
+    d.v, d.ldv, d.v_inst_stride, d.v_head_stride = kv_operand(v)
+    d.out, d.ldo = out.data_ptr(), out.stride(0)
+    d.instances, d.rows_per_inst, d.lk = int(instances), int(rows_per_inst), int(lk)
+    d.channels, d.heads, d.scale, d.dtype = 320, 8, float(scale), _dt(x)
+    second = None
+    if ln_out is not None:
+        g_, b_, eps_ = ln_out
+        _need_gpu(g_, b_)
+        second = torch.empty((rows, 320), dtype=x.dtype, device=x.device)
+        d.ln_out, d.ld_ln_out = second.data_ptr(), 320
+        d.ln_gamma, d.ln_beta, d.ln_eps = g_.data_ptr(), b_.data_ptr(), float(eps_)
+    e0 = _TIMER.start() if _TIMER is not None else None
+    _native.check(lib.dd_xattn320(ctypes.byref(d), _stream()), "xattn320")
+    if e0 is not None:      # 2 projections + attention; bytes: x in, out out (+ res, + ln_out), weights, K / V
+        _TIMER.stop(e0, "dd_xattn320_kernel", 4.0 * rows * 320 * 320 + 4.0 * rows * lk * 320,
+                    2.0 * (rows * 320 * (2 + (1 if res is not None else 0) + (1 if second is not None else 0))
+                           + 2 * 320 * 320 + 2 * instances * lk * 320))
+    if second is not None:
+        out._ln_out = second
     return out
 
 

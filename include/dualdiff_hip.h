@@ -246,6 +246,41 @@ typedef struct dd_attn_desc {
 int dd_attention(const dd_attn_desc* d, dd_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Fused cross-attention of the 320-channel level (8 heads x 40, <= 128 context keys per view-instance), ONE launch:
+ *   out[r, :] = ( softmax_j( scale * (x[r] Wq^T)_h . K[i, j]_h ) V[i, j]_h )_h Wo^T + bo + res[r, :]
+ * for query row r of view-instance i = r / rows_per_inst; optionally also ln_out = LayerNorm(out) (two-pass fp32
+ * statistics over the rounded values, eps ln_eps).  Replaces to_q -> memory_efficient_attention -> to_out (+ residual)
+ * of Semantic Fusion Attention (networks/txt_con_fusion.py:108-181: x = res = the ORS condition map, K / V = to_k /
+ * to_v of the 77 text tokens) and of the text / box cross-attention attn2 of the 28x50 transformer blocks
+ * (networks/box_adapter.py:102-163 inside blocks.py:166-187: x = LayerNorm2(h), res = h).  q and the attention output
+ * never reach HBM.  x / res / out: [instances * rows_per_inst][320] with row pitches ld* (elements).  K / V: element
+ * (instance i, key j, head h, d) at  k + i * k_inst_stride + j * ldk + h * k_head_stride + d  (elements; all strides
+ * multiples of 8) — row-major column slices of a wider projection (ldk = its width, head stride 40, instance stride
+ * lk * ldk) and head-major planes written by dd_gemm's out_headmajor_d = 40 (ldk = 40, head stride = total rows * 40,
+ * instance stride lk * 40: a head's keys are one contiguous block, which is what the kernel streams fastest).
+ * wq / wo: the [320][320] torch Linear weights PACKED by dd_xattn_pack_weight (K-step-major, pre-swizzled, so that the
+ * kernel's LDS-DMA copies them linearly); bo [320] (required: pass zeros for a bias-free projection).
+ * ------------------------------------------------------------------------- */
+typedef struct dd_xattn_desc {
+  const void* x; int64_t ldx;
+  const void* res; int64_t ldres;          /* NULL = no residual */
+  const void* wq; const void* wo; const void* bo;
+  const void* k; const void* v; int64_t ldk, ldv;
+  int64_t k_inst_stride, k_head_stride, v_inst_stride, v_head_stride;
+  void* out; int64_t ldo;
+  int32_t instances, rows_per_inst, lk;
+  int32_t channels, heads;                 /* 320, 8: anything else is DD_ERR_UNSUPPORTED */
+  float scale;
+  int32_t dtype;
+  void* ln_out; int64_t ld_ln_out;         /* NULL = off */
+  const void* ln_gamma; const void* ln_beta; float ln_eps;
+} dd_xattn_desc;
+
+int dd_xattn320(const dd_xattn_desc* d, dd_stream_t stream);
+/* w: [320][320] row-major (torch Linear: out x in) -> packed: 102,400 elements in the streaming order of dd_xattn320. */
+int dd_xattn_pack_weight(const void* w, void* packed, int32_t dtype, dd_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Small HBM-bound helpers.
  * ------------------------------------------------------------------------- */
 /* y = a + b (+ c)   — ControlNet residual add into UNet skips

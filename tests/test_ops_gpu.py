@@ -1089,3 +1089,102 @@ def test_attention_pair_rejects(ops):
         ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map2=mp)                    # needs kv_batch_map
     with pytest.raises(RuntimeError):
         ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map=mp, kv_batch_map2=mp, variant=7)   # default kernels only
+
+
+# ------------------------------------------------------------------ fused cross-attention (dd_xattn320) ----
+XATTN_CASES = [
+    # instances, rows per instance, keys, residual, bias, ln_out, K/V as column slices of a wider projection
+    (12, 1400, 77, True, True, False, False),      # SFA (txt_con_fusion.py), one scene
+    (6, 1400, 98, True, True, True, True),         # attn2 of a 28x50 block: K/V bank slices, emits the next LayerNorm
+    (3, 100, 98, True, True, True, True),          # ragged last tile (80 + 20 rows)
+    (2, 80, 128, False, False, False, False),      # exactly one tile, the maximum key count, no epilogue extras
+    (5, 37, 1, True, False, False, False),         # one key: softmax = 1
+    (4, 161, 17, False, True, True, False),
+    (2, 1400, 78, True, True, False, True),        # no boxes: 1 + 77 tokens
+    (6, 1400, 15, True, True, True, True),         # the short token lists of the end-to-end parity cases
+    (12, 1400, 9, True, True, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", XATTN_CASES, ids=lambda c: str(c))
+def test_xattn320_fused(ops, dtype, case):
+    """q-projection -> SDPA over the context keys -> out-projection + bias + residual (+ LayerNorm) in ONE launch vs
+    the fp32 leaf-op oracle and vs the three-launch path it replaces (same roundings: q, P and the attention output
+    in the storage type)."""
+    inst, n, lk, has_res, has_bias, has_ln, sliced = case
+    c, h, d = 320, 8, 40
+    rows = inst * n
+    x = rnd((rows, c), dtype, 1)
+    res = rnd((rows, c), dtype, 2) if has_res else None
+    wq = rnd((c, c), dtype, 3, c ** -0.5)
+    wo = rnd((c, c), dtype, 4, c ** -0.5)
+    bo = rnd((c,), dtype, 5) if has_bias else None
+    if sliced:                                       # K | V as columns 640.. of a [inst*lk, 3*640] bank
+        bank = rnd((inst * lk, 1920), dtype, 6)
+        k, v = bank[:, 640:960], bank[:, 960:1280]
+    else:
+        k, v = rnd((inst * lk, c), dtype, 6), rnd((inst * lk, c), dtype, 7)
+    g_, b_ = (1.0 + 0.1 * rnd((c,), torch.float32, 8)).to(dtype), rnd((c,), dtype, 9, 0.1)
+    scale = d ** -0.5
+    y = ops.xattn320(x, wq, wo, bo, k, v, inst, n, lk, scale, res=res, ln_out=(g_, b_, 1e-5) if has_ln else None)
+    # fp32 oracle
+    q_ref = L.linear_ref(x, wq, None)
+    o_ref = L.attention_ref(q_ref, k.float().cpu(), v.float().cpu(), inst, n, lk, h, d, scale)
+    ref = L.linear_ref(o_ref, wo, bo, res=res)
+    check(y, ref, dtype, "xattn320 %s" % (case,), 8.0)
+    # the three launches it replaces
+    q = ops.gemm(x, wq)
+    o = ops.attention(q, k, v, inst, n, lk, h, d, scale)
+    y3 = ops.gemm(o, wo, bo, res=res)
+    check(y, y3.float().cpu(), dtype, "xattn320 vs 3 launches %s" % (case,), 4.0)
+    # the same K / V handed over as head-major planes (8, instances * lk, 40): identical arithmetic -> identical bits
+    kh = k.reshape(inst * lk, h, d).permute(1, 0, 2).contiguous()
+    vh = v.reshape(inst * lk, h, d).permute(1, 0, 2).contiguous()
+    yh = ops.xattn320(x, wq, wo, bo, kh, vh, inst, n, lk, scale, res=res)
+    assert torch.equal(yh, y), "head-major K / V operands changed the result"
+    if has_ln:
+        ln_ref = L.layernorm_ref(y, g_, b_)          # LayerNorm of the values as stored
+        check(y._ln_out, ln_ref, dtype, "xattn320 ln_out %s" % (case,), 3.0)
+
+
+def test_xattn320_rejects(ops):
+    x = rnd((160, 320), torch.float16, 1)
+    w = rnd((320, 320), torch.float16, 2)
+    kv = rnd((2 * 129, 320), torch.float16, 3)
+    with pytest.raises(RuntimeError):
+        ops.xattn320(x, w, w, None, kv, kv, 2, 80, 129, 0.158)          # more than 128 keys
+    with pytest.raises(ValueError):
+        ops.xattn320(x[:, :312], w, w, None, kv[:256], kv[:256], 2, 80, 128, 0.158)
+
+
+def test_xattn320_concurrent_launches_bitwise(ops):
+    """The fused kernel moves every operand by LDS-DMA behind COUNTED vmcnt waits; a count that included instructions
+    whose lanes are all out of range (they retire at once, out of order) let a wait pass with an older weight slab still in
+    flight — invisible on an idle chip, wrong bits in 2 of 3 launches once other streams kept the memory system busy
+    (the dual-branch step runs three such launches side by side).  Three streams, different key counts, background
+    traffic: every result must equal the idle-chip result bit for bit."""
+    dt, n, c = torch.float16, 1400, 320
+    cases = []
+    for i, (inst, lk) in enumerate(((6, 15), (6, 9), (6, 98))):
+        x, res = rnd((inst * n, c), dt, 10 + i), rnd((inst * n, c), dt, 20 + i)
+        wq, wo, b = rnd((c, c), dt, 30 + i, c ** -0.5), rnd((c, c), dt, 40 + i, c ** -0.5), rnd((c,), dt, 50 + i)
+        bank = rnd((inst * lk, 1920), dt, 60 + i)
+        g_, b_ = rnd((c,), dt, 70 + i), rnd((c,), dt, 80 + i)
+        args = (x, wq, wo, b, bank[:, 640:960], bank[:, 960:1280], inst, n, lk, 40 ** -0.5)
+        ref = ops.xattn320(*args, res=res, ln_out=(g_, b_, 1e-5))
+        cases.append((args, res, (g_, b_, 1e-5), ref, ref._ln_out))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in cases]
+    big = torch.empty(1 << 27, dtype=torch.float16, device="cuda")
+    outs = []
+    for it in range(40):
+        for (args, res, ln, ref, lnref), st in zip(cases, streams):
+            with torch.cuda.stream(st):
+                y = ops.xattn320(*args, res=res, ln_out=ln)
+                outs.append((y, y._ln_out, ref, lnref))
+        if it % 3 == 0:
+            big.add_(1)
+    torch.cuda.synchronize()
+    bad = sum(1 for y, yl, ref, lnref in outs if not torch.equal(y, ref) or not torch.equal(yl, lnref))
+    assert bad == 0, "%d of %d concurrent launches differ from the idle-chip result" % (bad, len(outs))

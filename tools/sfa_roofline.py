@@ -62,3 +62,30 @@ for cls in (txt_con_XFormersAttn, txt_con_XFormersAttn_plus):
         t += row("to_out + bias + residual %dx%dx%d" % (rows, C, C), lambda: m.to_out[0].run(q, res=x),
                  2.0 * rows * C * C, 2.0 * (3 * rows * C + C * C))
         print("  sum of launches %.1f us; module as called %.1f us\n" % (t * 1e6, tw))
+
+# ---- round 3: the fused kernel (dd_xattn320: to_q -> SDPA over the text keys -> to_out + bias + residual, one launch) ----
+from dualdiff_amd.networks import layers as _layers
+m = txt_con_XFormersAttn().to(dev, dt)
+for p in m.parameters():
+    p.data.normal_(0, 0.03)
+with torch.no_grad():
+    for inst in (48, 12):
+        rows = inst * LQ
+        xx, ee = r(rows, C), r(inst * LK, 768)
+        kv = r(inst * LK, 2 * C)
+        kvh = r(2 * H, inst * LK, D)
+        print("fused txt_con_XFormersAttn (dd_xattn320), %d instances x %d tokens, %d text tokens, %s" % (inst, LQ, LK, str(dt).split(".")[-1]))
+        fl = 4.0 * rows * C * C + 4.0 * inst * H * LQ * LK * D
+        by = 2.0 * (3 * rows * C + 2 * C * C + inst * LK * 2 * C)          # x in, residual (the same tensor: L2), out
+        row("to_q + SDPA + to_out + bias + residual (1 launch)",
+            lambda: O.xattn320(xx, m.to_q.w2d, m.to_out[0].w2d, m.to_out[0].bias, kvh[:H], kvh[H:], inst, LQ, LK, D ** -0.5, res=xx),
+            fl, by)
+        row("  same, K / V as row-major column slices",
+            lambda: O.xattn320(xx, m.to_q.w2d, m.to_out[0].w2d, m.to_out[0].bias, kv[:, :C], kv[:, C:], inst, LQ, LK, D ** -0.5, res=xx),
+            fl, by)
+        for fused in (True, False):
+            _layers.XATTN_FUSED = fused
+            print("  module as called (to_k|to_v GEMM + %s): %.1f us" % ("fused kernel" if fused else "3 launches",
+                                                                          graph_time(lambda: m.run(xx, inst, LQ, ee, LK))))
+        _layers.XATTN_FUSED = True
+        print()
