@@ -1188,3 +1188,33 @@ def test_xattn320_concurrent_launches_bitwise(ops):
     torch.cuda.synchronize()
     bad = sum(1 for y, yl, ref, lnref in outs if not torch.equal(y, ref) or not torch.equal(yl, lnref))
     assert bad == 0, "%d of %d concurrent launches differ from the idle-chip result" % (bad, len(outs))
+
+
+def test_dma_gemm_conv_concurrent_launches_bitwise(ops):
+    """The same hazard class checked for the LDS-DMA GEMM / conv families (counted vmcnt waits over rings whose padding
+    taps and tile tails are out-of-range lanes): three streams + background traffic, idle-chip bits required."""
+    dt = torch.float16
+    cases = []
+    for i, (m, h, w, cin, cout, tile, split) in enumerate(((12, 28, 50, 320, 320, 28, 1), (12, 28, 50, 320, 320, 39, 1),
+                                                           (12, 14, 25, 640, 640, 12, 1), (12, 7, 13, 1280, 1280, 31, 4),
+                                                           (12, 4, 7, 1280, 1280, 37, 5), (12, 4, 7, 640, 1280, 13, 3))):
+        x, wt, b = rnd((m * h * w, cin), dt, i), rnd((cout, 9 * cin), dt, 10 + i, (9 * cin) ** -0.5), rnd((cout,), dt, 20 + i)
+        fn = (lambda x=x, wt=wt, b=b, m=m, h=h, w=w, tile=tile, split=split: ops.conv3x3(x, wt, b, m, h, w, tile=tile, split_k=split))
+        cases.append((fn, fn()))
+    for i, (rows, n, k, tile, split) in enumerate(((1092, 1280, 1280, 13, 1), (16800, 320, 320, 27, 1), (1003, 328, 2048, 12, 2))):
+        a, wt = rnd((rows, k), dt, 30 + i), rnd((n, k), dt, 40 + i, k ** -0.5)
+        fn = (lambda a=a, wt=wt, tile=tile, split=split: ops.gemm(a, wt, tile=tile, split_k=split))
+        cases.append((fn, fn()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    big = torch.empty(1 << 27, dtype=torch.float16, device="cuda")
+    outs = []
+    for it in range(15):
+        for ci, (fn, ref) in enumerate(cases):
+            with torch.cuda.stream(streams[(ci + it) % 3]):
+                outs.append((ci, fn(), ref))
+        if it % 2 == 0:
+            big.add_(1)
+    torch.cuda.synchronize()
+    bad = sorted({ci for ci, y, ref in outs if not torch.equal(y, ref)})
+    assert not bad, "cases with launches that differ from the idle-chip result: %s" % bad
