@@ -4,7 +4,7 @@
 # Every run uses the TRACKED tile table (dualdiff_amd/tuned/gfx950.json): same kernels in every process.
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -40,3 +40,5 @@ python3 $R/tools/pmc_mfma_summary.py /tmp/${TAG}_MFMA $OUT/${TAG}_pmc_mfma.csv
 python3 $R/tools/step_shapes.py > $OUT/${TAG}_step_shapes.txt 2>&1
 cat $OUT/${TAG}_bench.json | cut -c1-600
 cat $OUT/${TAG}_trace_summary.txt
+# 5. BASELINE configs[2]: the SFA module on its own (3-launch rows + the fused kernel, 48 and 12 instances)
+python3 $R/tools/sfa_roofline.py fp16 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_sfa_roofline.txt
