@@ -90,6 +90,9 @@ SIGNATURES = {
     "dd_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_scale": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p]),
     "dd_probe_spin": (c_int32, [c_void_p, c_uint32, c_void_p]),
+    "dd_groupnorm_splitk": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
+                                      c_int32, c_void_p]),
     "dd_xattn320": (c_int32, [POINTER(XAttnDesc), c_void_p]),
     "dd_xattn_pack_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "dd_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),

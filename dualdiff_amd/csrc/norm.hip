@@ -16,6 +16,13 @@ struct GnParams {
   int m, hw, groups, cpg; float eps; int silu;
   float* ws;          // [m][nsplit][groups][2]
   int nsplit, pix_per_split;
+  // split-K source (dd_groupnorm_splitk, single-launch form only): the input is NOT a tensor but the fp32 partial slabs
+  // of a split-K dd_gemm whose reduce launch this kernel replaces: x[r][c] = T( sum_z part[z][r][c] + bias[c]
+  // + rowvec[r / hw][c] + res[r][c] ), the arithmetic (and rounding) of dd_splitk_reduce_kernel's epilogue at alpha = 1.
+  const float* sk_part; int sk_nsplit; int64_t sk_rows;
+  const void* sk_bias; const void* sk_rowvec; int sk_ld_rowvec;
+  const void* sk_res; int64_t sk_ldres;
+  void* sk_xout;      // optional: the reduced tensor itself ([m * hw][c]), for consumers besides this GroupNorm
 };
 
 // thread -> (pixel lane, channel vector) mapping shared by both passes
@@ -49,6 +56,37 @@ constexpr int GN_UNROLL = 4;
 template <typename T>
 __device__ __forceinline__ float gn_pivot(const GnParams& p, int inst, int g) {
   return (float)*gn_src<T>(p, (int64_t)inst * p.hw, g * p.cpg);
+}
+
+// split-K source: 8 consecutive channels of one row, reduced over the slabs in slice order + the GEMM epilogue, rounded
+// to T exactly as dd_splitk_reduce_kernel stores them (bias, per-instance vector, residual; alpha = 1, no activation)
+template <typename T>
+__device__ __forceinline__ u32x4 gn_sk_load8(const GnParams& p, int64_t row, int ch, int inst) {
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.sk_nsplit; ++z) {
+    const float* src = p.sk_part + ((int64_t)z * p.sk_rows + row) * p.c + ch;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+    v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+    v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+  }
+  float b[8];
+  if (p.sk_bias) {
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.sk_bias) + ch), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (p.sk_rowvec) {
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.sk_rowvec) + (int64_t)inst * p.sk_ld_rowvec + ch), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (p.sk_res) {
+    dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.sk_res) + row * p.sk_ldres + ch), b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  return dd_pack8<T>(v);
 }
 
 template <typename T>
@@ -229,7 +267,7 @@ void dd_gn_apply_kernel(const GnParams p) {
 // (bit-reproducible), normalise + SiLU + store.  Used from the 14x25 level
 // down, where the two-launch path is pure launch + latency; 1024-thread blocks for the larger slabs
 // so that the per-thread VALU chain stays short.
-template <typename T, int THREADS, int NVMAX>
+template <typename T, int THREADS, int NVMAX, bool SK = false>
 __global__ __launch_bounds__(THREADS)
 void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int kred) {
   __shared__ float s_a0[THREADS], s_a1[THREADS], s_q0[THREADS], s_q1[THREADS];
@@ -249,7 +287,15 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
   u32x4 raw[NVMAX];
 #pragma unroll
   for (int i = 0; i < NVMAX; ++i)
-    if (i < nv) raw[i] = dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + min(pl + i * plc, p.hw - 1), ch));
+    if (i < nv) {
+      const int64_t row = (int64_t)inst * p.hw + min(pl + i * plc, p.hw - 1);
+      if constexpr (SK) {
+        raw[i] = gn_sk_load8<T>(p, row, ch, inst);
+        if (p.sk_xout && active && pl + i * plc < p.hw) dd_st16(reinterpret_cast<T*>(p.sk_xout) + row * p.c + ch, raw[i]);
+      } else {
+        raw[i] = dd_ld16(gn_src<T>(p, row, ch));
+      }
+    }
   const u32x4 graw = dd_ld16(reinterpret_cast<const T*>(p.gamma) + ch);
   const u32x4 braw = dd_ld16(reinterpret_cast<const T*>(p.beta) + ch);
   const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
@@ -257,9 +303,22 @@ void dd_gn_fused_kernel(const GnParams p, int cpb, int vpp, int plc, int nv, int
   // statistics in one pass (sum, sum of squares — the arithmetic of the two-launch path), reduced in
   // a fixed order (2 barriers, bit-reproducible).
   float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
-  const float piv0 = gn_pivot<T>(p, inst, blockIdx.x * gpb + g0);
-  const float piv1 = gn_pivot<T>(p, inst, blockIdx.x * gpb + g1);
-  if (t < gpb) s_piv[t] = gn_pivot<T>(p, inst, blockIdx.x * gpb + t);     // for the combine (no late global load)
+  auto pivot = [&](int g) -> float {
+    if constexpr (SK) {        // the group's first element of pixel 0, reduced like any other (8-channel aligned vector)
+      const int pc = g * p.cpg;
+      float f[8];
+      dd_unpack8<T>(gn_sk_load8<T>(p, (int64_t)inst * p.hw, pc & ~7, inst), f);
+      float r = f[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) r = (pc & 7) == e ? f[e] : r;
+      return r;
+    } else {
+      return gn_pivot<T>(p, inst, g);
+    }
+  };
+  const float piv0 = pivot(blockIdx.x * gpb + g0);
+  const float piv1 = pivot(blockIdx.x * gpb + g1);
+  if (t < gpb) s_piv[t] = pivot(blockIdx.x * gpb + t);     // for the combine (no late global load)
 #pragma unroll
   for (int i = 0; i < NVMAX; ++i) {
     if (i < nv) {
@@ -542,6 +601,38 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
   } else {
     hipLaunchKernelGGL(dd_gn_stats_kernel<__bf16>, grid, dim3(GN_THREADS), 0, s, p);
     hipLaunchKernelGGL(dd_gn_apply_kernel<__bf16>, grid, dim3(GN_THREADS), 0, s, p);
+  }
+  return dd_check_launch();
+}
+
+extern "C" int dd_groupnorm_splitk(const float* partial, int32_t nsplit, const void* bias, const void* rowvec,
+                                   int32_t ld_rowvec, const void* res, int64_t ldres, void* x_out,
+                                   const void* gamma, const void* beta, void* y, int32_t m, int32_t hw, int32_t c,
+                                   int32_t groups, float eps, int32_t apply_silu, int32_t dtype, dd_stream_t stream) {
+  if (!partial || !gamma || !beta || !y || nsplit < 2 || nsplit > 64) return DD_ERR_BAD_ARG;
+  if (m <= 0 || hw <= 0 || groups <= 0 || groups > 64 || c <= 0 || (c & 7) || c % groups || c > GN_MAX_C) return DD_ERR_BAD_ARG;
+  if (c / groups < 4) return DD_ERR_UNSUPPORTED;
+  if (dtype != DD_F16 && dtype != DD_BF16) return DD_ERR_BAD_ARG;
+  if (!dd_aligned16(partial) || !dd_aligned16(y) || !dd_aligned16(gamma) || !dd_aligned16(beta) ||
+      (bias && !dd_aligned16(bias)) || (rowvec && (!dd_aligned16(rowvec) || (ld_rowvec & 7))) ||
+      (res && (!dd_aligned16(res) || (ldres & 7))) || (x_out && !dd_aligned16(x_out))) return DD_ERR_BAD_ARG;
+  int cpb, vpp, plc, nv, kred, threads;
+  if (!gn_fused_plan(hw, c, groups, &cpb, &vpp, &plc, &nv, &kred, &threads)) return DD_ERR_UNSUPPORTED;
+  GnParams p{};
+  p.x1 = nullptr; p.c1 = c; p.c = c;
+  p.gamma = gamma; p.beta = beta; p.y = y;
+  p.m = m; p.hw = hw; p.groups = groups; p.cpg = c / groups; p.eps = eps; p.silu = apply_silu;
+  p.sk_part = partial; p.sk_nsplit = nsplit; p.sk_rows = (int64_t)m * hw;
+  p.sk_bias = bias; p.sk_rowvec = rowvec; p.sk_ld_rowvec = ld_rowvec; p.sk_res = res; p.sk_ldres = ldres; p.sk_xout = x_out;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dd_clear_error();
+  dim3 fgrid(c / cpb, m);
+  if (threads == 256) {
+    if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_fused_kernel<_Float16, 256, GNF_NV_SMALL, true>), fgrid, dim3(256), 0, s, p, cpb, vpp, plc, nv, kred);
+    else hipLaunchKernelGGL((dd_gn_fused_kernel<__bf16, 256, GNF_NV_SMALL, true>), fgrid, dim3(256), 0, s, p, cpb, vpp, plc, nv, kred);
+  } else {
+    if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_fused_kernel<_Float16, 1024, GNF_NV_BIG, true>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
+    else hipLaunchKernelGGL((dd_gn_fused_kernel<__bf16, 1024, GNF_NV_BIG, true>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
   }
   return dd_check_launch();
 }

@@ -160,6 +160,7 @@ class Conv3x3(_Cached):
         return self.__dict__["_pk_w"]
 
     def run(self, x2d, m, h, w, up_size=None, **kw):
+        """kw gn_next = (GroupNorm module, silu, want_x): see ops.conv3x3 (split-K reduce folded into that norm)."""
         return O.conv3x3(x2d, self.packed, self.bias, m, h, w, stride=self.stride, up_size=up_size, **kw)
 
     def out_hw(self, h, w, up_size=None):
@@ -182,6 +183,13 @@ class GroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.empty(num_channels))
 
     def run(self, x2d, m, hw, silu, x2=None):
+        hit = getattr(x2d, "_gn_cache", None)          # already computed by the producing conv's fused reduce + norm
+        if hit is not None:
+            del x2d._gn_cache                          # consumed once (see LayerNorm.run)
+            if hit[0] is self and hit[1] == bool(silu) and x2 is None:
+                return hit[2]
+        if getattr(x2d, "_unwritten", False):
+            raise RuntimeError("this conv output was folded into its GroupNorm and never written")
         return O.groupnorm(x2d, self.weight, self.bias, m, hw, self.num_groups, self.eps, silu, x2=x2)
 
 
@@ -346,12 +354,14 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = Conv3x3(out_channels, out_channels)
         self.conv_shortcut = Linear(in_channels, out_channels, conv=True) if in_channels != out_channels else None
 
-    def run(self, x, m, h, w, temb_vec, x2=None, extra_res=None):
+    def run(self, x, m, h, w, temb_vec, x2=None, extra_res=None, gn_next=None):
         """x: (mhw, c1) [, x2: (mhw, c2)]; temb_vec: (m, cout) = time_emb_proj(SiLU(emb)) view.
-        extra_res: optional second residual added to the output (ControlNet mid residual)."""
+        extra_res: optional second residual added to the output (ControlNet mid residual).
+        gn_next: the single-source GroupNorm module that reads the block's output next (the Transformer2DModel input
+        norm), so that a split-K conv2 can hand its reduction to it."""
         hw = h * w
         a = self.norm1.run(x, m, hw, True, x2=x2)
-        hid = self.conv1.run(a, m, h, w, rowvec=temb_vec)
+        hid = self.conv1.run(a, m, h, w, rowvec=temb_vec, gn_next=(self.norm2, True, False))
         a = self.norm2.run(hid, m, hw, True)
         if self.conv_shortcut is not None:
             sc = self.conv_shortcut.run(x, a2=x2, res=extra_res)
@@ -359,7 +369,7 @@ class ResnetBlock2D(nn.Module):
             sc = O.add(x, extra_res)
         else:
             sc = x
-        return self.conv2.run(a, m, h, w, res=sc)
+        return self.conv2.run(a, m, h, w, res=sc, gn_next=None if gn_next is None else (gn_next, False, True))
 
 
 class Downsample2D(nn.Module):
@@ -731,7 +741,8 @@ def run_down_block(blk, x, m, h, w, temb_slices, ctx2d, lc):
     """-> (x, h, w, [skip tensors with their (h, w)])."""
     skips = []
     for i, resnet in enumerate(blk.resnets):
-        x = resnet.run(x, m, h, w, temb_slices[id(resnet)])
+        x = resnet.run(x, m, h, w, temb_slices[id(resnet)],
+                       gn_next=blk.attentions[i].norm if blk.attentions is not None else None)
         if blk.attentions is not None:
             x = blk.attentions[i].run(x, m, h, w, ctx2d, lc)
         skips.append((x, h, w))
@@ -756,7 +767,7 @@ class UNetMidBlock2DCrossAttn(nn.Module):
                                block_cls, block_kwargs)])
 
     def run(self, x, m, h, w, temb_slices, ctx2d, lc, extra_res=None):
-        x = self.resnets[0].run(x, m, h, w, temb_slices[id(self.resnets[0])])
+        x = self.resnets[0].run(x, m, h, w, temb_slices[id(self.resnets[0])], gn_next=self.attentions[0].norm)
         x = self.attentions[0].run(x, m, h, w, ctx2d, lc)
         return self.resnets[1].run(x, m, h, w, temb_slices[id(self.resnets[1])], extra_res=extra_res)
 
@@ -801,7 +812,8 @@ def run_up_block(blk, x, m, h, w, skips, temb_slices, ctx2d, lc, up_size):
     for i, resnet in enumerate(blk.resnets):
         s, sh, sw = skips.pop()
         assert (sh, sw) == (h, w)
-        x = resnet.run(x, m, h, w, temb_slices[id(resnet)], x2=s)
+        x = resnet.run(x, m, h, w, temb_slices[id(resnet)], x2=s,
+                       gn_next=blk.attentions[i].norm if blk.attentions is not None else None)
         if blk.attentions is not None:
             x = blk.attentions[i].run(x, m, h, w, ctx2d, lc)
     if blk.upsamplers is not None:

@@ -388,7 +388,7 @@ def _timed_gemm(lib, d, what, suffix, flops, nbytes, rows, n):
 def _forget_derived(t):
     """A tensor that is about to be (re)written through its data pointer loses whatever an earlier producer
     attached to it (LayerNorm emitted by an epilogue, row statistics): those describe the OLD contents."""
-    for a in ("_ln_cache", "_ln_out", "_ln_stats"):
+    for a in ("_ln_cache", "_ln_out", "_ln_stats", "_gn_cache", "_unwritten"):
         if hasattr(t, a):
             delattr(t, a)
 
@@ -542,6 +542,8 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
 
 
 _THIN_CONV = _os.environ.get("DD_THIN_CONV", "1") != "0"       # A/B switch of dd_conv3x3_thin
+# split-K reduce folded into the GroupNorm that consumes the conv's output (dd_groupnorm_splitk); DD_GN_SPLITK=0: off
+GN_SPLITK = _os.environ.get("DD_GN_SPLITK", "1") != "0"
 
 
 def thin_conv_ok(cin, cout, stride, m):
@@ -550,8 +552,14 @@ def thin_conv_ok(cin, cout, stride, m):
 
 
 def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res=None,
-            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, splitk_inkernel=0):
+            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, splitk_inkernel=0,
+            gn_next=None):
     """3x3 / pad 1 convolution as an implicit GEMM on an NHWC batch.
+
+    gn_next = (GroupNorm module, silu, want_x): the GroupNorm that reads this conv's output next.  When the conv runs
+    split-K (two launches) and the image takes the single-launch GroupNorm, the REDUCE launch is replaced by
+    dd_groupnorm_splitk: it adds the slabs, applies the epilogue and normalises in one go; the result is attached as
+    `out._gn_cache` (GroupNorm.run picks it up) and `out` itself is written only if want_x.
 
     x: (m*hin*win, cin); w: (cout, 9*cin) packed [cout][ky][kx][cin]; optional nearest
     upsample of x to `up_size` first; rowvec: (m, cout) per-instance vector (time embedding).
@@ -610,6 +618,33 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     if need > 0 or _DBG_STAMP_WS:
         ws = workspace(need, x.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
+    if gn_next is not None and GN_SPLITK and need > 0 and alpha == 1.0 and not accumulate and epilogue == DD_EPI_NONE:
+        gmod, gsilu, want_x = gn_next
+        _, split, ink = _kname(lib, d)
+        if split > 1 and not ink and lib.dd_groupnorm_is_fused(hout * wout, cout, gmod.num_groups):
+            # partial slabs only; dd_groupnorm_splitk is reduce + epilogue + GroupNorm(+SiLU) in one launch
+            y = torch.empty((rows, cout), dtype=x.dtype, device=x.device)
+            d.phase = 1
+            e0 = _TIMER.start() if _TIMER is not None else None
+            _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), "conv3x3")
+            if e0 is not None:
+                name = _kname(lib, d)[0]
+                _TIMER.stop(e0, name + (" conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else ""),
+                            2.0 * rows * cout * 9 * cin, 2.0 * (x.numel() + w.numel()) + 4.0 * split * rows * cout,
+                            _staged_bytes(lib, d))
+                e0 = _TIMER.start()
+            rc = lib.dd_groupnorm_splitk(ctypes.c_void_p(ws.data_ptr() + 65536), split, _ptr(bias), _ptr(rowvec),
+                                         rowvec.stride(0) if rowvec is not None else 0, _ptr(res),
+                                         res.stride(0) if res is not None else 0, _ptr(out) if want_x else None,
+                                         _ptr(gmod.weight), _ptr(gmod.bias), _ptr(y), m, hout * wout, cout,
+                                         gmod.num_groups, float(gmod.eps), int(gsilu), _dt(x), _stream())
+            _native.check(rc, "groupnorm_splitk")
+            if e0 is not None:
+                _TIMER.stop(e0, "dd_gn_splitk_kernel", 0.0, 4.0 * split * rows * cout + 2.0 * rows * cout * (2 if want_x else 1))
+            out._gn_cache = (gmod, bool(gsilu), y)
+            if not want_x:
+                out._unwritten = True          # nobody but that GroupNorm may read it
+            return out
     if _TIMER is not None:
         _timed_gemm(lib, d, "conv3x3", " conv %dx%dx%d" % (rows, cout, 9 * cin) if _TIMER.shapes else "",
                     2.0 * rows * cout * 9 * cin,

@@ -203,6 +203,17 @@ int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups);
  * (for profile matching, like dd_gemm_kernel_name). */
 int dd_groupnorm_is_fused(int32_t hw, int32_t c, int32_t groups);
 
+/* GroupNorm(+SiLU) that CONSUMES the partial slabs of a split-K dd_gemm launched with phase = 1 (in place of that GEMM's
+ * reduce launch): x[r, c] = T( sum_z partial[z][r][c] + bias[c] + rowvec[r / hw][c] + res[r][c] ) — exactly what the
+ * reduce launch would have stored (alpha = 1, no activation, no accumulate) — then y = GroupNorm(x) as above; x itself
+ * is written only when x_out != NULL.  ResnetBlock2D: conv1 -> norm2 (x is not needed) and conv2 -> the Transformer2D
+ * input norm (x is the residual stream).  partial = (char*)ws + 65536 of the dd_gemm call, nsplit = its slice count
+ * (dd_gemm_kernel_name reports it).  Single-launch images only (dd_groupnorm_is_fused != 0), else DD_ERR_UNSUPPORTED. */
+int dd_groupnorm_splitk(const float* partial, int32_t nsplit, const void* bias, const void* rowvec, int32_t ld_rowvec,
+                        const void* res, int64_t ldres, void* x_out, const void* gamma, const void* beta, void* y,
+                        int32_t m, int32_t hw, int32_t c, int32_t groups, float eps, int32_t apply_silu, int32_t dtype,
+                        dd_stream_t stream);
+
 /* LayerNorm over the last dim (eps 1e-5, affine) — BasicTransformerBlock
  * norm1/2/3 (diffusers) and norm4 (networks/blocks.py:67-71,191-194). */
 int dd_layernorm(const void* x, const void* gamma, const void* beta, void* y,

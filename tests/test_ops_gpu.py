@@ -1218,3 +1218,37 @@ def test_dma_gemm_conv_concurrent_launches_bitwise(ops):
     torch.cuda.synchronize()
     bad = sorted({ci for ci, y, ref in outs if not torch.equal(y, ref)})
     assert not bad, "cases with launches that differ from the idle-chip result: %s" % bad
+
+
+# ------------------------------------------------------------------ split-K reduce folded into the consuming GroupNorm ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(12, 14, 25, 640, 640, 31, 2), (12, 7, 13, 1280, 1280, 31, 4), (12, 4, 7, 1280, 1280, 37, 5),
+                                  (12, 4, 7, 2560, 1280, 31, 12), (5, 7, 13, 640, 1280, 12, 3), (3, 14, 25, 320, 640, 31, 2)],
+                         ids=lambda c: str(c))
+@pytest.mark.parametrize("silu,want_x", [(True, False), (False, True)])
+def test_conv_splitk_reduce_folded_into_groupnorm(ops, dtype, case, silu, want_x):
+    """dd_groupnorm_splitk (round 3): the GroupNorm that reads a split-K conv's output adds the slabs, applies the conv's
+    epilogue (bias + time vector + residual) and normalises in ONE launch — in place of the reduce launch + GroupNorm.
+    Same arithmetic in the same order: bit-identical to the two-step form (both for y and, when kept, for x)."""
+    from dualdiff_amd.networks.layers import GroupNorm
+    m, h, w_, cin, cout, tile, split = case
+    x = rnd((m * h * w_, cin), dtype, 1)
+    w = L.pack_conv_weight(rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5))
+    b = rnd((cout,), dtype, 3)
+    temb = rnd((m, cout), dtype, 4)
+    res = rnd((m * h * w_, cout), dtype, 5) if want_x else None
+    gn = GroupNorm(32, cout, 1e-6 if want_x else 1e-5).to("cuda", dtype)
+    with torch.no_grad():
+        gn.weight.copy_(1.0 + 0.1 * rnd((cout,), torch.float32, 6))
+        gn.bias.copy_(rnd((cout,), torch.float32, 7, 0.1))
+    ref_x = ops.conv3x3(x, w, b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split)
+    ref_y = gn.run(ref_x, m, h * w_, silu)
+    out = ops.conv3x3(x, w, b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split, gn_next=(gn, silu, want_x))
+    assert getattr(out, "_gn_cache", None) is not None, "the fused reduce + GroupNorm path was not taken"
+    y = gn.run(out, m, h * w_, silu)
+    assert torch.equal(y, ref_y)
+    if want_x:
+        assert torch.equal(out, ref_x)
+    else:
+        with pytest.raises(RuntimeError):
+            gn.run(out, m, h * w_, silu)              # the cache is consumed once and x was never written
