@@ -69,6 +69,17 @@ class XAttnDesc(Structure):
     ]
 
 
+class Gemm8Desc(Structure):
+    _fields_ = [
+        ("a", c_void_p), ("a_scale", c_void_p), ("lda", c_int64),
+        ("w", c_void_p), ("w_scale", c_void_p), ("ldw", c_int64),
+        ("bias", c_void_p), ("res", c_void_p), ("ldres", c_int64),
+        ("out", c_void_p), ("ldc", c_int64),
+        ("rows", c_int32), ("n", c_int32), ("k_padded", c_int32), ("dtype", c_int32),
+        ("out_headmajor_d", c_int32), ("hm_scaled_planes", c_int32), ("hm_scale", c_float), ("geglu", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "dd_abi_version": (c_int32, []),
@@ -94,6 +105,9 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                       c_int32, c_void_p]),
     "dd_xattn320": (c_int32, [POINTER(XAttnDesc), c_void_p]),
+    "dd_gemm8": (c_int32, [POINTER(Gemm8Desc), c_void_p]),
+    "dd_rowquant_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_float,
+                                  c_int32, c_void_p]),
     "dd_xattn_pack_weight": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "dd_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -1818,6 +1818,10 @@ constexpr TileCfg kTiles[] = {
     // 26.5 -> 23.2 us cold, 1092x1280x6400: 41.4 -> 37.6)
     {44, 4, 2, 3, 4, 3, "192x128/dma3"},
     {46, 4, 2, 3, 4, 2, "192x128/dma2"},
+    // 256x256 (round 3): the tiled family is bound by L2 -> LDS staging, and staged bytes per flop go with
+    // (BM + BN) / (BM * BN): 0.0078 B/flop against 0.0117 for 256x128.  8 waves of 128 x 64 (32 accumulator blocks per
+    // wave: one wave per SIMD pair, 2 stages of 64 KB).  Candidates for the wide GEGLU projections and the big convs.
+    {50, 2, 4, 8, 4, 2, "256x256/dma2"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -2143,6 +2147,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
     case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
     case 40: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 1, 10, 5, 2, 2, false, false>(p, pl, s); break;
+    case 50: return launch_cfg2<T, 2, 4, 8, 4, 2, CONV, GEGLU>(p, pl, s);
     case 44: return launch_cfg2<T, 4, 2, 3, 4, 3, CONV, GEGLU>(p, pl, s);
     case 46: return launch_cfg2<T, 4, 2, 3, 4, 2, CONV, GEGLU>(p, pl, s);
     case 29: if constexpr (GEGLU) return launch_cfg2<T, 2, 5, 5, 4, 2, false, true>(p, pl, s); break;   // 168 VGPRs: only the GEGLU form fits without spills

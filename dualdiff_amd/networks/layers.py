@@ -79,6 +79,14 @@ class Linear(_Cached):
         return self.__dict__["_pk_w"]
 
     fp8 = False        # extension (BASELINE configs[4]): multiply by e4m3fn weights + per-channel scales
+    fp8_mfma = False   # extension: W8A8 on the fp8 matrix path (dd_gemm8) where it pays: K >= 640 and a wide output
+
+    @property
+    def w8p(self):
+        """(float8_e4m3fn [n, K padded to 128], fp32 scale [n]): the W8 operand of ops.gemm8, packed lazily."""
+        if "_pk_w8p" not in self.__dict__:
+            self.__dict__["_pk_w8p"] = O.quantize_fp8_padded(self.w2d)
+        return self.__dict__["_pk_w8p"]
 
     @property
     def w8(self):
@@ -111,6 +119,12 @@ class Linear(_Cached):
     def run_ln(self, x2d, norm, **kw):
         """LayerNorm(norm) + this Linear.  Row-panel GEMM with the LayerNorm as its prologue where the family
         covers the shape (ln_direct_ok), else the algebraic fold when enabled, else two launches."""
+        if self.fp8_mfma and fp8_mfma_ok(norm, self.in_features, self.out_features, x2d) \
+                and set(kw) <= {"epilogue"} and kw.get("epilogue", O.DD_EPI_NONE) in (O.DD_EPI_NONE, O.DD_EPI_GEGLU):
+            # the LayerNorm launch quantises its output rows to e4m3; the projection runs on the fp8 matrix path
+            a8, sa = O.rowquant_fp8(x2d, (norm.weight, norm.bias, norm.eps))
+            w8, sw = self.w8p
+            return O.gemm8(a8, sa, w8, sw, self.bias, dtype=x2d.dtype, geglu=kw.get("epilogue") == O.DD_EPI_GEGLU)
         if ln_direct_ok(norm, self.in_features, self.out_features, kw):
             if self._fp8_ok(kw):
                 w8, sc = self.w8
@@ -268,6 +282,14 @@ def ln_producer_ok(lin, norm, kw):
     bad = ("ln", "ln_direct", "ln_stats", "head_major", "out_f32", "accumulate", "rowvec", "out", "tile", "split_k")
     return not any(kw.get(k) for k in bad) and kw.get("epilogue", O.DD_EPI_NONE) == O.DD_EPI_NONE \
         and kw.get("alpha", 1.0) == 1.0
+
+
+def fp8_mfma_ok(norm, k, n, x2d):
+    """Where the W8A8 projection beats LayerNorm + 16-bit GEMM on MI355X (tools/gemm8_bench.py): K = 640 / 1280 and an
+    output at least 3 K wide (fused Q|K|V, the GEGLU projection); the C x C projections and the 320-channel level
+    (K padded 320 -> 384, three K steps) do not gain and stay 16-bit."""
+    return isinstance(norm, LayerNorm) and k in (640, 1280) and n >= 3 * k and x2d.is_contiguous() \
+        and getattr(x2d, "_ln_cache", None) is None
 
 
 def ln_direct_ok(norm, k, n, kw=None):
@@ -473,6 +495,7 @@ class Attention(_Cached):
         return self.__dict__[key]
 
     fp8 = False        # extension: fused Q|K|V projection with e4m3fn weights (enable_fp8_weights)
+    fp8_mfma = False   # extension: ... and e4m3fn activations on the fp8 matrix path (enable_fp8_weights(mfma=True))
 
     def _fused_fp8(self, names):
         key = "_pk_w8_" + "".join(names)
@@ -491,6 +514,13 @@ class Attention(_Cached):
         folded into the GEMM."""
         hm = self._hm(self.heads) if head_major else None
         names = ("to_q", "to_k", "to_v")
+        if self.fp8_mfma and norm is not None and fp8_mfma_ok(norm, x2d.shape[1], 3 * self.inner_dim, x2d):
+            key = "_pk_w8p_qkv"
+            if key not in self.__dict__:
+                self.__dict__[key] = O.quantize_fp8_padded(self._fused(names))
+            w8, sw = self.__dict__[key]
+            a8, sa = O.rowquant_fp8(x2d, (norm.weight, norm.bias, norm.eps))
+            return O.gemm8(a8, sa, w8, sw, self._fused_bias(names), head_major=hm, dtype=x2d.dtype)
         if self.fp8 and O.rowpanel_ok(x2d.shape[1], 3 * self.inner_dim):
             w8, sc = self._fused_fp8(names)
             if norm is not None and ln_direct_ok(norm, x2d.shape[1], 3 * self.inner_dim):
@@ -562,21 +592,33 @@ class Attention(_Cached):
                               attention_mask=attention_mask, **kw)
 
 
-def enable_fp8_weights(model, on=True):
-    """EXTENSION (BASELINE configs[4], no reference semantics): every attention projection of `model` whose shape
-    the row-panel GEMM family covers (fused Q|K|V, to_q, to_out — K = C of the level) multiplies by e4m3fn
-    weights with per-output-channel scales (half the weight stream; fragments are dequantised once per kernel
-    when they enter registers).  Quantisation happens lazily from the CURRENT weights, so fold LoRA deltas
-    first (dualdiff_amd.lora.fold_lora_).  Returns the number of layers switched."""
+def enable_fp8_weights(model, on=True, mfma=False):
+    """EXTENSION (BASELINE configs[4], no reference semantics).  Two forms:
+
+    mfma=False (round 2): every attention projection of `model` whose shape the row-panel GEMM family covers (fused
+    Q|K|V, to_q, to_out — K = C of the level) multiplies by e4m3fn weights with per-output-channel scales; fragments are
+    dequantised once when they enter registers, the matrix instruction is the 16-bit one.
+
+    mfma=True (round 3, "CDNA4 fp8 MFMA"): W8A8 — the LayerNorm in front of the fused Q|K|V projections (attn1, attn4,
+    the video block's attn_temp) and of the GEGLU projection quantises its output rows to e4m3fn (dd_rowquant_fp8) and
+    the projection runs on v_mfma_scale_f32_16x16x128_f8f6f4 (dd_gemm8), wherever that is faster than the 16-bit pair
+    (K = 640 / 1280, output >= 3 K wide: fp8_mfma_ok); everything else stays 16-bit.
+
+    Quantisation happens lazily from the CURRENT weights, so fold LoRA deltas first (dualdiff_amd.lora.fold_lora_).
+    Returns the number of attention layers switched."""
     n = 0
     for mod in model.modules():
         if isinstance(mod, Attention):
-            mod.fp8 = bool(on)
+            mod.fp8 = bool(on) and not mfma
+            mod.fp8_mfma = bool(on) and bool(mfma)
             mod._drop_cache()
             for lin in (mod.to_q, mod.to_out[0]):
-                lin.fp8 = bool(on)
+                lin.fp8 = bool(on) and not mfma
                 lin._drop_cache()
             n += 1
+        elif isinstance(mod, GEGLU):
+            mod.proj.fp8_mfma = bool(on) and bool(mfma)
+            mod.proj._drop_cache()
     return n
 
 

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _native
-from ._native import DD_BF16, DD_EPI_GEGLU, DD_EPI_NONE, DD_EPI_SILU, DD_F16, AttnDesc, GemmDesc, XAttnDesc
+from ._native import DD_BF16, DD_EPI_GEGLU, DD_EPI_NONE, DD_EPI_SILU, DD_F16, AttnDesc, Gemm8Desc, GemmDesc, XAttnDesc
 
 _WS = {}
 _WS_MIN_BYTES = 64 << 20
@@ -1051,6 +1051,92 @@ def quantize_fp8(w):
     scale = (wf.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
     q = (wf / scale[:, None]).to(torch.float8_e4m3fn).contiguous()
     return q, scale
+
+
+def _kpad(k):
+    return (int(k) + 127) // 128 * 128
+
+
+def quantize_fp8_padded(w):
+    """[n, k] weight -> (float8_e4m3fn [n, k rounded up to 128] with zero padding, fp32 scale [n]): the W8 operand of
+    gemm8 (per-output-channel symmetric quantisation, the values quantize_fp8 produces)."""
+    q, scale = quantize_fp8(w)
+    kp = _kpad(w.shape[1])
+    if kp != w.shape[1]:
+        qp = torch.zeros((w.shape[0], kp), dtype=torch.uint8, device=w.device)
+        qp[:, :w.shape[1]] = q.view(torch.uint8)
+        q = qp.view(torch.float8_e4m3fn)
+    return q.contiguous(), scale
+
+
+def rowquant_fp8(x, norm=None):
+    """Per-row e4m3fn quantisation of the activations (dd_rowquant_fp8), optionally behind LayerNorm `norm =
+    (gamma, beta, eps)` in the same launch -> (float8_e4m3fn [rows, k rounded up to 128], fp32 scale [rows])."""
+    lib = _native.load()
+    _need_gpu(x)
+    x = _rows2d(x)
+    if not x.is_contiguous():
+        raise ValueError("rowquant_fp8 input must be contiguous")
+    rows, c = x.shape
+    kp = _kpad(c)
+    q = torch.empty((rows, kp), dtype=torch.uint8, device=x.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    g_, b_, eps_ = norm if norm is not None else (None, None, 0.0)
+    e0 = _TIMER.start() if _TIMER is not None else None
+    _native.check(lib.dd_rowquant_fp8(_ptr(x), _ptr(g_), _ptr(b_), _ptr(q), _ptr(scale), rows, c, kp, float(eps_), _dt(x),
+                                      _stream()), "rowquant_fp8")
+    if e0 is not None:
+        _TIMER.stop(e0, "dd_rowquant_fp8_kernel", 0.0, 2.0 * rows * c + rows * kp)
+    return q.view(torch.float8_e4m3fn), scale
+
+
+def gemm8(a8, a_scale, w8, w_scale, bias=None, *, res=None, out=None, head_major=None, dtype=torch.float16, geglu=False):
+    """W8A8 projection on the fp8 matrix path (include/dualdiff_hip.h: dd_gemm8): a8 (rows, Kp) / w8 (n, Kp)
+    float8_e4m3fn with rows zero-padded to Kp % 128 == 0, fp32 per-row / per-output-channel scales.  head_major as in
+    gemm(): the result comes back as (n / D, rows, D) planes, the first `scaled_planes` multiplied by `scale`."""
+    lib = _native.load()
+    _need_gpu(a8, a_scale, w8, w_scale, bias, res, out)
+    if a8.dtype != torch.float8_e4m3fn or w8.dtype != torch.float8_e4m3fn or a8.shape[1] != w8.shape[1] \
+            or a8.shape[1] % 128 or not a8.is_contiguous() or not w8.is_contiguous():
+        raise ValueError("gemm8 operands must be contiguous float8_e4m3fn with a common K padded to a multiple of 128")
+    rows, n = a8.shape[0], w8.shape[0]
+    if geglu:
+        if n % 2 or res is not None or head_major is not None:
+            raise ValueError("geglu: w8 has 2n rows (h | g), no residual, no head-major output")
+    if a_scale.numel() != rows or w_scale.numel() != n or a_scale.dtype != torch.float32 or w_scale.dtype != torch.float32:
+        raise ValueError("gemm8 scales must be fp32 [rows] / [n]")
+    hm_out = None
+    d = Gemm8Desc()
+    if head_major is not None:
+        hd, hplanes, hscale = head_major
+        if out is not None or res is not None or n % hd or hd % 4:
+            raise ValueError("head_major needs its own output, no residual and n % D == 0")
+        hm_out = torch.empty((n // hd, rows, hd), dtype=dtype, device=a8.device)
+        out = hm_out.view(rows, n)
+        d.out_headmajor_d, d.hm_scaled_planes, d.hm_scale = int(hd), int(hplanes), float(hscale)
+    if out is None:
+        out = torch.empty((rows, n // 2 if geglu else n), dtype=dtype, device=a8.device)
+    else:
+        _forget_derived(out)
+    out = _rows2d(out)
+    d.a, d.a_scale, d.lda = a8.data_ptr(), a_scale.data_ptr(), a8.stride(0)
+    d.w, d.w_scale, d.ldw = w8.data_ptr(), w_scale.data_ptr(), w8.stride(0)
+    d.bias = bias.data_ptr() if bias is not None else None
+    if res is not None:
+        res = _rows2d(res)
+        d.res, d.ldres = res.data_ptr(), res.stride(0)
+    d.out, d.ldc = out.data_ptr(), out.stride(0)
+    if geglu:
+        n //= 2
+        d.geglu = 1
+    d.rows, d.n, d.k_padded = rows, n, a8.shape[1]
+    d.dtype = _dt(out)
+    e0 = _TIMER.start() if _TIMER is not None else None
+    _native.check(lib.dd_gemm8(ctypes.byref(d), _stream()), "gemm8")
+    if e0 is not None:
+        _TIMER.stop(e0, "dd_gemm8_kernel", 2.0 * rows * n * a8.shape[1],
+                    1.0 * (rows + n) * a8.shape[1] + 2.0 * rows * n * (1 + (1 if res is not None else 0)))
+    return hm_out if hm_out is not None else out
 
 
 def rowpanel_ok(k, n):

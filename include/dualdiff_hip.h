@@ -390,6 +390,35 @@ int dd_cfg_unipc_step(const void* eps, const void* x, void* x_out, void* x_dup, 
                       float* m2, const float* coef, float guidance, int64_t n, int32_t dtype,
                       dd_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * EXTENSION (BASELINE configs[4]: "fp8 weights (CDNA4 fp8 MFMA)"; no reference semantics — README.md:47-49 is prose):
+ * W8A8 projection on the fp8 matrix path.
+ *   dd_rowquant_fp8: y = gamma ? LayerNorm(x) (dd_layernorm's arithmetic, rounded to the storage type) : x;
+ *       scale[r] = max_c |y[r, c]| / 448 (1 for a zero row);  q[r, c] = e4m3fn(y[r, c] / scale[r]) (round to nearest even);
+ *       q rows have pitch ldq bytes (multiple of 128, zero padded) — the LayerNorm launch of norm1 / norm2 / norm4
+ *       (networks/blocks.py:150-222) doubles as the activation quantiser.
+ *   dd_gemm8: out[r, n] = a_scale[r] * w_scale[n] * sum_k A8[r, k] W8[n, k] + bias[n] + res[r, n], fp32 accumulation in
+ *       v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), A8 [rows][lda] / W8 [n][ldw] OCP e4m3fn bytes whose rows are
+ *       zero padded to k_padded (multiple of 128); output in `dtype`, row-major or head-major planes as dd_gemm's
+ *       out_headmajor_d (the fused Q|K|V projection of attn1 / attn4, to_q of attn2), or with the GEGLU gate.
+ * ------------------------------------------------------------------------- */
+int dd_rowquant_fp8(const void* x, const void* gamma, const void* beta, void* q, float* scale, int64_t rows, int32_t c,
+                    int64_t ldq, float eps, int32_t dtype, dd_stream_t stream);
+
+typedef struct dd_gemm8_desc {
+  const void* a; const float* a_scale; int64_t lda;
+  const void* w; const float* w_scale; int64_t ldw;
+  const void* bias; const void* res; int64_t ldres;
+  void* out; int64_t ldc;
+  int32_t rows, n, k_padded;
+  int32_t dtype;                          /* of bias / res / out */
+  int32_t out_headmajor_d, hm_scaled_planes; float hm_scale;
+  int32_t geglu;                          /* 1: W8 / w_scale / bias have 2n rows (h | g); out[r, c] = h * gelu_erf(g) — the
+                                             GEGLU projection of FeedForward behind norm3 (diffusers FeedForward / GEGLU) */
+} dd_gemm8_desc;
+
+int dd_gemm8(const dd_gemm8_desc* d, dd_stream_t stream);
+
 /* Measurement aid (not on the data path): one wave busy-waits `ticks_100mhz` ticks of the constant-rate 100 MHz
  * s_memrealtime counter and stores its first and last counter reading in stamps[0], stamps[1] (device memory).
  * bench.py brackets it with HIP events to learn what an event pair adds to a kernel of KNOWN device-side duration. */

@@ -281,3 +281,33 @@ def test_view_split_two_ranks_rccl():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("VIEW_SPLIT_RCCL")][-1]
     err = float(line.split("rel_l2=")[1].split()[0])
     assert err <= 2e-3, line
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_fp8_mfma_lora_video_unet_16_frames(gpu, dtype):
+    """EXTENSION, configs[4] at its stated size on the fp8 MATRIX path (round 3: W8A8, dd_gemm8): the whole 16-frame video
+    UNet (one CFG half = 96 instances) with a folded rank-4 LoRA and enable_fp8_weights(mfma=True) — finite, and within the
+    quantisation noise of two e4m3 operands of the same network in 16 bit (the op-level tests of tests/test_fp8_mfma_gpu.py
+    pin the arithmetic exactly; here the bound only guards against a broken path at full size)."""
+    from dualdiff_amd.lora import fold_lora_, lora_keys
+    from dualdiff_amd.networks.layers import device_init_, enable_fp8_weights
+    from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiviewVideo
+    frames, m = 16, 96
+    with torch.device("cuda"):
+        net = UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames).to(dtype)
+    device_init_(net, 3)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    lora = {k: torch.randn(shape, generator=g, device="cuda") * 0.02 for k, shape in sorted(lora_keys(net, 4).items())}
+    fold_lora_(net, lora, 1.0)
+    net.eval()
+    x = torch.randn((m, 4, C.H, C.W), generator=g, device="cuda").to(dtype)
+    ctx = torch.randn((m, 98, 768), generator=g, device="cuda").to(dtype)
+    with torch.no_grad():
+        y16 = net(x, 481, encoder_hidden_states=ctx).sample.float().cpu()
+        enable_fp8_weights(net, mfma=True)
+        y8 = net(x, 481, encoder_hidden_states=ctx).sample.float().cpu()
+    e = rel_l2(y8, y16)
+    print("fp8 MFMA (W8A8) + LoRA video UNet, 16 frames: vs 16-bit rel-L2 %.3e" % e)
+    from tests.parity_util import log_row
+    log_row("fp8 MFMA W8A8 + LoRA video unet T=16 vs 16-bit", dtype, e, 0.0, 1e-1)
+    assert torch.isfinite(y8).all() and 1e-4 < e < 1e-1
