@@ -703,8 +703,17 @@ constexpr uint32_t DD_OOB = 0x80000000u;
 #define DD_STAMP(i) do {} while (0)
 #endif
 
+// Occupancy target (round 3): the DENSE four-wave instantiations had grown to 240-272 registers (LayerNorm fold, row
+// statistics, head-major planes, persistent walk ... all live in one body), i.e. ONE wave per SIMD and one workgroup per CU
+// although their 48-72 KB rings would let two in — the situation in which a latency-bound K loop has nothing to hide
+// behind.  Where two rings fit the LDS the compiler is told to fit two workgroups (<= 256 registers per wave).
+template <int NW, int TM, int TN, int NSTAGE, bool CONV>
+constexpr int gemm2_min_blocks() {
+  return (!CONV && NW == 4 && TM * TN <= 8 && NSTAGE <= 3) ? 2 : 1;
+}
+
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (gemm2_min_blocks<WAVES_M * WAVES_N, TM, TN, NSTAGE, CONV>()))
 void dd_gemm2_kernel(const GemmParams p) {
   using V8 = typename dd_vec<T>::v8;
   constexpr int NW = WAVES_M * WAVES_N;

@@ -51,13 +51,17 @@ def main():
     g = torch.Generator().manual_seed(2024)
     proj = torch.randn((4 * 28 * 50, 64), generator=g) / (4 * 28 * 50) ** 0.5
     a = sample(False, n_scenes, steps, rank)
-    b = sample(True, n_scenes, steps, rank)
-    fa, fb = (a @ proj).numpy(), (b @ proj).numpy()
+    fa = (a @ proj).numpy()
     half = fa.shape[0] // 2
     out = {"metric": "Frechet distance in a fixed 64-d random projection of the final latents — NOT FID",
            "scenes": n_scenes, "views": 6, "ddim_steps": steps, "lora_rank_folded": rank,
-           "fd_fp8_vs_16bit": frechet(fa, fb), "fd_16bit_half_vs_half": frechet(fa[:half], fa[half:]),
-           "rel_l2_latents_fp8_vs_16bit": float((a - b).norm() / a.norm())}
+           "fd_16bit_half_vs_half": frechet(fa[:half], fa[half:])}
+    # "mfma": W8A8 on the fp8 matrix instruction (round 3, bench.py --fp8-weights); "weights": e4m3 weights only (round 2)
+    for mode in ("mfma", "weights"):
+        b = sample(mode, n_scenes, steps, rank)
+        fb = (b @ proj).numpy()
+        out["fd_fp8_%s_vs_16bit" % mode] = frechet(fa, fb)
+        out["rel_l2_latents_fp8_%s_vs_16bit" % mode] = float((a - b).norm() / a.norm())
     print(json.dumps(out))
 
 
