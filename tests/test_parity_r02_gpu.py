@@ -164,7 +164,7 @@ def test_full_step_dual_branch_bf16_vs_oracle(step_models):
 def test_trajectory_50_steps_fp16(step_models):
     """One whole 50-step DDIM sample in fp16 (the reference's dtype) replayed from the HIP graph, compared at
     the checkpoints with the fp32 oracle trajectory; the fp16-storage oracle trajectory is the floor.  The
-    drift curve goes to the parity CSV.  Bound: max(1e-3, 1.0 x floor) at EVERY checkpoint (measured: the HIP
+    drift curve goes to the parity CSV.  Bound: max(1e-3, 1.02 x floor) at EVERY checkpoint (measured: the HIP
     curve stays just below the floor's all the way, 1.46e-3 vs 1.47e-3 after 50 steps)."""
     g = _gold()
     dtype = torch.float16
