@@ -126,9 +126,9 @@ class Adapter_XFormersAttnProcessor(torch.nn.Module):
 
 def box_adapter(net, use_box_token=False):
     """Installs the adapter on every text cross-attention of `net`, initialised from that layer's own
-    to_k / to_v (box_adapter.py:414-444); attn1 / attn4 keep the plain processor."""
-    if use_box_token:
-        raise NotImplementedError("use_box_token (boxworld feature tokens) is unused by the reference configs")
+    to_k / to_v (box_adapter.py:414-444); attn1 / attn4 keep the plain processor.  use_box_token (:441-442): the
+    adapter projections take 128-wide boxworld feature tokens and keep nn.Linear's default initialisation, as in the
+    reference — whose processor then raises NotImplementedError for the token-list context (:269-270), as this one does."""
     sd = net.state_dict()
     procs = {}
     for name in list(net.attn_processors.keys()):
@@ -137,6 +137,12 @@ def box_adapter(net, use_box_token=False):
             continue
         layer = name[: -len(".processor")]
         wk, wv = sd[layer + ".to_k.weight"], sd[layer + ".to_v.weight"]
+        if use_box_token:
+            p = Adapter_XFormersAttnProcessor(hidden_size=wk.shape[0], cross_attention_dim=128)
+            for lin in (p.to_k_box, p.to_v_box, p.to_k_cls, p.to_v_cls):
+                torch.nn.init.kaiming_uniform_(lin.weight, a=math.sqrt(5))          # nn.Linear.reset_parameters
+            procs[name] = p.to(device=wk.device, dtype=wk.dtype)
+            continue
         p = Adapter_XFormersAttnProcessor(hidden_size=wk.shape[0], cross_attention_dim=wk.shape[1])
         p.load_state_dict({"to_k_box.weight": wk, "to_v_box.weight": wv, "to_k_cls.weight": wk, "to_v_cls.weight": wv})
         procs[name] = p.to(device=wk.device, dtype=wk.dtype)

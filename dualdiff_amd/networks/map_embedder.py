@@ -52,11 +52,57 @@ class ControlNetConditioningEmbedding(nn.Module):
 
 
 class BEVControlNetConditioningEmbedding(nn.Module):
-    """BEV-map embedder of vanilla MagicDrive (map_embedder.py:10-77); not used by the DualDiff
-    ORS branches (configs/exp/dual_branch_augloss_fusion.yaml) — kept as a named stub so configs
-    that reference it fail with a clear message."""
+    """BEV-map embedder of vanilla MagicDrive (map_embedder.py:10-77); the DualDiff ORS branches
+    (configs/exp/dual_branch_augloss_fusion.yaml) use ControlNetConditioningEmbedding instead.  The (b, 25, 200, 200) map is
+    shared by the 6 views (`repeat(... repeat=6)`, :65): it is embedded ONCE per scene and the result is repeated.
 
-    def __init__(self, *a, **k):
+    The reference's asymmetric paddings / strides map onto the pad-1 HIP conv without new arithmetic:
+      padding (2, 1)            one extra zero row above and below the NHWC activation, then the pad-1 conv;
+      stride 2, padding (2, 1)  the same extra rows, then the stride-2 pad-1 conv (output row i reads input rows 2i-2..2i);
+      stride (2, 1)             the stride-1 conv, every second output ROW kept (the same taps in the same order, so the kept
+                                rows carry the bits a dedicated kernel would produce; the embedder runs on 54x50 maps).
+    200x200 -> 101x100 -> 52x50 -> 54x50 -> 28x50 with the default widths; SiLU after every conv but the last."""
+
+    def __init__(self, conditioning_embedding_channels: int = 320, conditioning_size: Tuple[int, int, int] = (25, 200, 200),
+                 block_out_channels: Tuple[int, ...] = (32, 64, 128, 256)):
         super().__init__()
-        raise NotImplementedError("BEVControlNetConditioningEmbedding is outside the DualDiff hot path "
-                                  "(SURVEY.md §8a A11); use ControlNetConditioningEmbedding")
+        self.conv_in = Conv3x3(conditioning_size[0], block_out_channels[0])
+        self.blocks = nn.ModuleList([])
+        self._geom = []                                   # per block: (extra zero rows, keep every k-th output row)
+        for i in range(len(block_out_channels) - 2):
+            ci, co = block_out_channels[i], block_out_channels[i + 1]
+            self.blocks.append(Conv3x3(ci, ci))
+            self.blocks.append(Conv3x3(ci, co, stride=2))
+            self._geom += [(0, 1), (1, 1)]
+        ci, co = block_out_channels[-2], block_out_channels[-1]
+        self.blocks.append(Conv3x3(ci, ci))
+        self.blocks.append(Conv3x3(ci, co))
+        self._geom += [(1, 1), (1, 2)]
+        self.conv_out = Conv3x3(co, conditioning_embedding_channels)
+
+    def run(self, conditioning, n_views=6):
+        """(b, c, h, w) NCHW map -> ((b * n_views * h' * w'), C) NHWC rows, b * n_views, h', w'."""
+        b, c, h, w = conditioning.shape
+        dt = self.conv_in.weight.dtype
+        xp = conditioning.new_zeros((b, h, w, self.conv_in.cin_pad), dtype=dt)
+        xp[..., :c] = conditioning.to(dt).permute(0, 2, 3, 1)
+        x = self.conv_in.run(xp.reshape(b * h * w, -1), b, h, w, epilogue=O.DD_EPI_SILU)
+        for blk, (rows, keep) in zip(self.blocks, self._geom):
+            ch = x.shape[1]
+            if rows:
+                x = torch.nn.functional.pad(x.reshape(b, h, w, ch), (0, 0, 0, 0, rows, rows)).reshape(-1, ch)
+                h += 2 * rows
+            x = blk.run(x, b, h, w, epilogue=O.DD_EPI_SILU)
+            h, w = blk.out_hw(h, w)
+            if keep > 1:
+                x = x.reshape(b, h, w, -1)[:, ::keep].contiguous()
+                h = x.shape[1]
+                x = x.reshape(b * h * w, -1)
+        y = self.conv_out.run(x, b, h, w)
+        nv = int(n_views)
+        y = y.reshape(b, 1, h * w, -1).expand(b, nv, h * w, y.shape[-1]).reshape(b * nv * h * w, -1)
+        return y, b * nv, h, w
+
+    def forward(self, conditioning):
+        x, m, h, w = self.run(conditioning)
+        return as_nchw_view(x, m, h, w)

@@ -348,3 +348,15 @@ class UNet2DConditionModelMultiviewVideo(UNet2DConditionModelMultiview):
             if isinstance(mod, VideoMultiviewTransformerBlock):
                 mod.n_frames = int(n_frames)
         self.config["n_frames"] = int(n_frames)
+
+    def set_frame_shard(self, shard):
+        """Frame split (parallel.FrameShard): this rank holds `shard.plan.local` of the n_frames frames
+        of every scene (all views of a frame local); None restores the unsharded model."""
+        from .video_blocks import VideoMultiviewTransformerBlock
+        blocks = [mod for mod in self.modules() if isinstance(mod, VideoMultiviewTransformerBlock)]
+        if shard is not None and any(b.n_frames != shard.plan.n_frames for b in blocks):
+            raise ValueError("frame shard plans %d frames, the model is configured for %d"
+                             % (shard.plan.n_frames, blocks[0].n_frames))
+        for mod in blocks:
+            mod.frame_shard = shard
+        self.frame_shard = shard

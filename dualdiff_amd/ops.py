@@ -542,8 +542,11 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
 
 
 _THIN_CONV = _os.environ.get("DD_THIN_CONV", "1") != "0"       # A/B switch of dd_conv3x3_thin
-# split-K reduce folded into the GroupNorm that consumes the conv's output (dd_groupnorm_splitk); DD_GN_SPLITK=0: off
-GN_SPLITK = _os.environ.get("DD_GN_SPLITK", "1") != "0"
+# split-K reduce folded into the GroupNorm that consumes the conv's output (dd_groupnorm_splitk): 50 launches fewer per
+# step, bit-identical — and 0.5 % SLOWER on the step (84.9 vs 85.4 steps/s over three alternating pairs: the norm then
+# reads `split` fp32 slabs with the few workgroups a 28-pixel image gives it, where the separate reduce spreads them over
+# the chip), so it is OFF by default; DD_GN_SPLITK=1 turns it on
+GN_SPLITK = _os.environ.get("DD_GN_SPLITK", "0") == "1"
 
 
 def thin_conv_ok(cin, cout, stride, m):
@@ -699,7 +702,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_map=None,
               out=None, accumulate=False, variant=0, q_prescaled=False, seq_strides=None,
-              out_seq_strides=None, kv_batch_map2=None):
+              out_seq_strides=None, kv_batch_map2=None, kv_seq_strides=None):
     """softmax(scale * q k^T) v per (batch, head).
 
     q / k / v may also be HEAD-MAJOR 3-D tensors (heads, rows, head_dim) — slices of a
@@ -713,11 +716,14 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     seq_strides = (row_stride, batch_stride) in elements for q, k, v (row-major 2-D views with the same row
     pitch), out_seq_strides likewise for `out` (default: the same): the sequence runs over rows `row_stride`
     apart and consecutive batches start `batch_stride` apart — attention ALONG ANOTHER AXIS of a (frames, tokens, C) activation without a transpose
-    (temporal attention: row_stride = tokens_per_frame * C, batch_stride = C)."""
+    (temporal attention: row_stride = tokens_per_frame * C, batch_stride = C).  kv_seq_strides: the same pair for k / v
+    when they live in another buffer than q (frame-split temporal attention: local queries, gathered keys)."""
     lib = _native.load()
     _need_gpu(q, k, v, out, kv_batch_map, kv_batch_map2)
     if kv_batch_map2 is not None and (kv_batch_map is None or seq_strides is not None):
         raise ValueError("kv_batch_map2 needs kv_batch_map and no seq_strides")
+    if kv_seq_strides is not None and seq_strides is None:
+        raise ValueError("kv_seq_strides needs seq_strides")
     d = AttnDesc()
 
     def operand(t, l):
@@ -750,8 +756,9 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
             raise ValueError("seq_strides takes row-major 2-D q / k / v and no kv_batch_map")
         rs, bs = int(seq_strides[0]), int(seq_strides[1])
         ors, obs = (rs, bs) if out_seq_strides is None else (int(out_seq_strides[0]), int(out_seq_strides[1]))
-        d.ldq = d.ldk = d.ldv = rs
-        d.q_batch_stride = d.k_batch_stride = d.v_batch_stride = bs
+        krs, kbs = (rs, bs) if kv_seq_strides is None else (int(kv_seq_strides[0]), int(kv_seq_strides[1]))
+        d.ldq, d.ldk, d.ldv = rs, krs, krs
+        d.q_batch_stride, d.k_batch_stride, d.v_batch_stride = bs, kbs, kbs
         d.ldo, d.o_batch_stride = ors, obs
     d.batch, d.heads, d.head_dim, d.lq, d.lk = batch, heads, head_dim, lq, lk
     d.scale = float(scale) if scale is not None else head_dim ** -0.5
@@ -767,7 +774,8 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
         base = (d.q, d.k, d.v, d.o)
         for b0 in range(0, batch, per):
             d.batch = min(per, batch - b0)
-            d.q, d.k, d.v = (ptr + b0 * d.q_batch_stride * es for ptr in base[:3])
+            d.q = base[0] + b0 * d.q_batch_stride * es
+            d.k, d.v = base[1] + b0 * d.k_batch_stride * es, base[2] + b0 * d.v_batch_stride * es
             d.o = base[3] + b0 * d.o_batch_stride * es
             _native.check(lib.dd_attention(ctypes.byref(d), _stream()), "attention")
         return out

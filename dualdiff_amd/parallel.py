@@ -245,3 +245,138 @@ class ViewShard:
         n = self.plan.n_cam
         lo, hi = self.plan.local[0], self.plan.local[-1] + 1
         return t.reshape(nb, n, *t.shape[1:])[:, lo:hi].reshape(nb * (hi - lo), *t.shape[1:])
+
+
+# ------------------------------------------------------------------------------------------------
+# Frame split (EXTENSION — BASELINE configs[3]/[4]): the T frames of a scene over several GPUs,
+# all 6 views of a frame local.  Instances stay ordered scene-major, then (local) frame, then view, so every
+# per-instance layer, the ControlNets, cross-attention AND the cross-view attention (attn4: neighbours of a
+# view are views of the SAME frame) run unchanged on fewer instances.  What crosses ranks, per video block
+# (networks/video_blocks.py):
+#   ST-Attn   every frame attends to [first frame ; previous frame]: the owner of frame 0 sends its K/V to every
+#             other rank, and each rank sends the K/V of its LAST frame to the next rank — point to point;
+#   temporal  attention over the T frames of every token position: queries stay local, the K|V rows of all
+#             frames are all-gathered (frame-major, so a rank's contribution is one contiguous block).
+# ------------------------------------------------------------------------------------------------
+class FrameSplitPlan:
+    """Static plan of one rank: contiguous, balanced frame ranges in rank order (first ranks take the remainder)."""
+
+    def __init__(self, world, rank, n_frames):
+        if not (1 <= world <= n_frames):
+            raise ValueError("cannot split %d frames over %d ranks" % (n_frames, world))
+        self.world, self.rank, self.n_frames = world, rank, int(n_frames)
+        self.ranges = [shard_scenes(self.n_frames, r, world) for r in range(world)]
+        self.lo, self.hi = self.ranges[rank]
+        self.local = list(range(self.lo, self.hi))
+
+    @property
+    def n_local(self):
+        return self.hi - self.lo
+
+    def counts(self):
+        return [hi - lo for lo, hi in self.ranges]
+
+    def message_bytes(self, n_tokens, channels, n_views=6, nb=1, elem=2):
+        """(ST-Attn bytes sent, temporal all-gather bytes received) by this rank per video block at a level."""
+        frame_kv = 2 * n_views * n_tokens * channels * elem * nb
+        st = (self.world - 1) * frame_kv if self.rank == 0 else 0
+        st += frame_kv if self.rank + 1 < self.world else 0
+        return st, (self.n_frames - self.n_local) * frame_kv
+
+
+class FrameExchange:
+    """The two exchanges of a frame-sharded video block.  RCCL: device tensors travel as they are; gloo (CPU tests,
+    shared-GPU plumbing mode): device tensors are staged through host memory, as in HaloExchange."""
+
+    def __init__(self, plan, group=None):
+        self.plan, self.group = plan, group
+
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _rank(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def st_sources(self, first_local, last_local):
+        """K/V of this rank's first / last local frame (contiguous, equal shapes) -> (K/V of frame 0, K/V of the
+        frame before this rank's first one).  Rank 0 gets its own first frame twice (frame 0's previous frame is
+        frame 0, video_blocks.py)."""
+        pl = self.plan
+        if pl.world == 1:
+            return first_local, first_local
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("FrameExchange needs an initialised process group")
+        staged = self._staged(first_local)
+        ops, holds = [], []
+
+        def out(t):
+            t = t.cpu() if staged else t
+            holds.append(t)
+            return t
+
+        def landing():
+            return torch.empty(first_local.shape, dtype=first_local.dtype, device="cpu" if staged else first_local.device)
+        first = prev = None
+        # posting order is the same on both ends of every pair: [frame-0 message, last-frame message]
+        if pl.rank == 0:
+            for r in range(1, pl.world):
+                ops.append(dist.P2POp(dist.isend, out(first_local), self._rank(r), self.group))
+        else:
+            first = landing()
+            ops.append(dist.P2POp(dist.irecv, first, self._rank(0), self.group))
+        if pl.rank + 1 < pl.world:
+            ops.append(dist.P2POp(dist.isend, out(last_local), self._rank(pl.rank + 1), self.group))
+        if pl.rank > 0:
+            prev = landing()
+            ops.append(dist.P2POp(dist.irecv, prev, self._rank(pl.rank - 1), self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if pl.rank == 0:
+            return first_local, first_local
+        if staged:
+            first, prev = first.to(first_local.device), prev.to(first_local.device)
+        return first, prev
+
+    def gather_frames(self, local):
+        """(n_local frames, ...) contiguous -> (n_frames, ...) in frame order on every rank."""
+        pl = self.plan
+        if pl.world == 1:
+            return local
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("FrameExchange needs an initialised process group")
+        staged = self._staged(local)
+        src = local.cpu() if staged else local.contiguous()
+        counts, mx = pl.counts(), max(pl.counts())
+        if mx != src.shape[0]:                                       # ragged split: pad to the largest shard
+            pad = torch.zeros((mx,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            pad[: src.shape[0]] = src
+            src = pad
+        if len(set(counts)) == 1:
+            out = torch.empty((pl.n_frames,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            dist.all_gather(list(out.split(mx)), src, group=self.group)
+        else:
+            parts = [torch.empty_like(src) for _ in counts]
+            dist.all_gather(parts, src, group=self.group)
+            out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+        return out.to(local.device) if staged else out
+
+
+class FrameShard:
+    """Run-time handle of a frame-sharded video UNet (`UNet2DConditionModelMultiviewVideo.set_frame_shard`): the
+    plan plus the exchange (FrameExchange, or an in-process stand-in with the same two methods)."""
+
+    def __init__(self, plan, exchange=None):
+        self.plan = plan
+        self.exchange = exchange if exchange is not None else FrameExchange(plan)
+
+    @property
+    def n_local(self):
+        return self.plan.n_local
+
+    def take_frames(self, t, nb, per_frame):
+        """(nb * T * per_frame, ...) instances ordered scene, frame, view -> this rank's frames of every scene."""
+        pl = self.plan
+        if t.shape[0] != nb * pl.n_frames * per_frame:
+            raise ValueError("dim 0 of %s is not %d scenes x %d frames x %d" % (tuple(t.shape), nb, pl.n_frames, per_frame))
+        return t.reshape(nb, pl.n_frames, per_frame, *t.shape[1:])[:, pl.lo:pl.hi] \
+            .reshape(nb * pl.n_local * per_frame, *t.shape[1:])

@@ -121,6 +121,34 @@ class ControlNetConditioningEmbedding(nn.Module):
         return self.conv_out(x)
 
 
+class BEVControlNetConditioningEmbedding(nn.Module):
+    """networks/map_embedder.py:10-77 (vanilla MagicDrive's BEV-map embedder; unused by the DualDiff ORS configs):
+    the (b, 25, 200, 200) map is repeated for the 6 views, conv 25->32, then [c->c pad 1 | c->c' pad (2, 1) stride 2]
+    for the first len-2 stages, [c->c pad (2, 1) | c->c' pad (2, 1) stride (2, 1)] for the last one — 200x200 ->
+    101x100 -> 52x50 -> 54x50 -> 28x50 — SiLU after every conv, zero-init conv 256->320."""
+
+    def __init__(self, conditioning_embedding_channels=320, conditioning_size=(25, 200, 200),
+                 block_out_channels=(32, 64, 128, 256)):
+        super().__init__()
+        self.conv_in = nn.Conv2d(conditioning_size[0], block_out_channels[0], 3, padding=1)
+        self.blocks = nn.ModuleList()
+        for i in range(len(block_out_channels) - 2):
+            ci, co = block_out_channels[i], block_out_channels[i + 1]
+            self.blocks.append(nn.Conv2d(ci, ci, 3, padding=1))
+            self.blocks.append(nn.Conv2d(ci, co, 3, padding=(2, 1), stride=2))
+        ci, co = block_out_channels[-2], block_out_channels[-1]
+        self.blocks.append(nn.Conv2d(ci, ci, 3, padding=(2, 1)))
+        self.blocks.append(nn.Conv2d(ci, co, 3, padding=(2, 1), stride=(2, 1)))
+        self.conv_out = D.zero_module(nn.Conv2d(co, conditioning_embedding_channels, 3, padding=1))
+
+    def forward(self, conditioning):
+        x = conditioning.repeat_interleave(6, dim=0)                  # 'b ... -> (b repeat) ...'
+        x = F.silu(self.conv_in(x))
+        for blk in self.blocks:
+            x = F.silu(blk(x))
+        return self.conv_out(x)
+
+
 class BBoxEmbedder(nn.Module):
     """networks/bbox_embedder.py:28-203 `ContinuousBBoxWithTextEmbedding` (mode 'all-xyz',
     minmax_normalize False): Fourier(8 corners x 3) -> Linear -> SiLU -> cat class token ->

@@ -26,6 +26,15 @@ def cond_image():
     return torch.rand((1, 3, 224, 2400), generator=g)
 
 
+SEED_BEV_EMB = 27
+
+
+def bev_map():
+    """(1, 25, 200, 200) binary-ish BEV map layers (map_embedder.py:23 conditioning_size)."""
+    g = torch.Generator().manual_seed(107)
+    return (torch.rand((1, 25, 200, 200), generator=g) > 0.7).float()
+
+
 def box_inputs():
     g = torch.Generator().manual_seed(104)
     bb = (torch.rand((12, 5, 8, 3), generator=g) - 0.5) * 100.0

@@ -13,7 +13,7 @@ copied):
 
 Consequences for pinning (DESIGN.md "Oracle"):
   LEVEL 1 (true reference arithmetic; only the SDPA stand-in is ours):
-      sfa, sfa_plus, cond_embedder, bbox_embedder, attn_processor, adapter_processor,
+      sfa, sfa_plus, cond_embedder, bev_map_embedder, bbox_embedder, attn_processor, adapter_processor,
       ors_projection (integer labels, bit-exact)
   LEVEL 2 (reference control flow executed verbatim over our restated leaf modules):
       multiview_block, unet_multiview, controlnet_bg, controlnet_fg, controlnet_bg_adapter
@@ -269,6 +269,17 @@ def mint_ors():
                                                       sorted(set(labels.unique().tolist()))))
 
 
+@torch.no_grad()
+def mint_bev_embedder():
+    """`python tests/golden/mint.py bev`: the reference's BEVControlNetConditioningEmbedding (level 1: its own arithmetic)."""
+    install_stubs()
+    from oracle import dualdiff_restated as R
+    from magicdrive.networks import map_embedder as ref_map
+    ref = ref_map.BEVControlNetConditioningEmbedding()
+    load_from(ref, R.BEVControlNetConditioningEmbedding(), C.SEED_BEV_EMB)
+    save("bev_map_embedder", out=ref(C.bev_map()))
+
+
 def _self_attn():
     a = D.Attention(query_dim=320, heads=8, dim_head=40)
     a.load_state_dict(seeded_state_dict(a, C.SEED_PROC + 1))
@@ -281,7 +292,10 @@ if __name__ == "__main__":
         mint_ors()
     elif len(sys.argv) > 1 and sys.argv[1] == "variants":
         mint_block_variants()
+    elif len(sys.argv) > 1 and sys.argv[1] == "bev":
+        mint_bev_embedder()
     else:
         main()
         mint_ors()
         mint_block_variants()
+        mint_bev_embedder()

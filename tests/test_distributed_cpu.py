@@ -239,3 +239,56 @@ def test_bench_gpus_flag_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--plumbing-check"],
                        capture_output=True, text=True, env=e, timeout=300)
     assert r.returncode != 0 and "--gpus 3" in (r.stderr + r.stdout)
+
+
+# ---------------------------------------------------------------- frame split (extension) ----
+def _frame_worker(rank, world, port, n_frames, out):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from dualdiff_amd.parallel import FrameExchange, FrameShard, FrameSplitPlan
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = FrameSplitPlan(world, rank, n_frames)
+    shard = FrameShard(plan, FrameExchange(plan))
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn((n_frames, 2, 5, 4), generator=g)              # per-frame K/V stand-in, same on every rank
+    local = full[plan.lo:plan.hi].contiguous()
+    first, prev = shard.exchange.st_sources(local[0].contiguous(), local[-1].contiguous())
+    ok_st = torch.equal(first, full[0]) and torch.equal(prev, full[max(plan.lo - 1, 0)])
+    ok_all = torch.equal(shard.exchange.gather_frames(local), full)
+    inst = torch.arange(3 * n_frames * 6).reshape(3 * n_frames * 6, 1)      # 3 scenes x T frames x 6 views
+    took = shard.take_frames(inst, 3, 6).reshape(3, plan.n_local, 6)
+    ok_take = torch.equal(took, inst.reshape(3, n_frames, 6)[:, plan.lo:plan.hi])
+    out.put((rank, plan.local, bool(ok_st), bool(ok_all), bool(ok_take), plan.message_bytes(1400, 320)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (3, 8), (4, 4), (2, 3)])
+def test_frame_split_exchange_gloo(world, n_frames):
+    """Frames of a scene sharded over `world` ranks (balanced and ragged): the ST-Attn sources (frame 0 from rank 0,
+    the previous frame from the rank before) and the temporal all-gather arrive bit for bit; the ranges tile [0, T)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frame_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum((g[1] for g in got), []) == list(range(n_frames))
+    assert all(g[2] and g[3] and g[4] for g in got), got
+    frame_kv = 2 * 6 * 1400 * 320 * 2
+    assert got[0][5][0] == world * frame_kv if world > 1 else 0           # rank 0: frame 0 to everyone + its last frame
+    assert got[-1][5] == (0, (n_frames - len(got[-1][1])) * frame_kv)      # last rank sends nothing
+
+
+def test_frame_split_plan_rejects_more_ranks_than_frames():
+    from dualdiff_amd.parallel import FrameSplitPlan
+    with pytest.raises(ValueError):
+        FrameSplitPlan(4, 0, 3)

@@ -75,6 +75,26 @@ def test_attn_processor_registry():
     assert all(type(p) is HIPAttnProcessor for p in net.attn_processors.values())
 
 
+def test_box_adapter_use_box_token_installer():
+    """box_adapter.py:441-442: with use_box_token the adapter projections take the 128-wide boxworld feature tokens (no
+    copy of to_k / to_v); the token-LIST context itself raises NotImplementedError in the reference's processor
+    (:269-270) and here; attn1 / attn4 keep the plain processor."""
+    from dualdiff_amd.networks.box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor, box_adapter
+    net = small_unet()
+    box_adapter(net, use_box_token=True)
+    procs = net.attn_processors
+    ad = {k: p for k, p in procs.items() if isinstance(p, Adapter_XFormersAttnProcessor)}
+    assert ad and all(k.endswith("attn2.processor") for k in ad)
+    assert all(type(p) is XFormersAttnProcessor for k, p in procs.items() if k not in ad)
+    for p in ad.values():
+        assert p.to_k_box.weight.shape[1] == 128 and p.to_v_cls.weight.shape[1] == 128
+        assert torch.isfinite(p.to_k_box.weight).all() and p.to_k_box.weight.abs().max() > 0
+    name, p = next(iter(ad.items()))
+    attn = dict(net.named_modules())[name[: -len(".processor")]]
+    with pytest.raises(NotImplementedError):
+        p(attn, torch.zeros(1, 4, attn.to_q.in_features), [torch.zeros(1, 3, 768), torch.zeros(1, 2, 128, 1)])
+
+
 def small_cnet():
     from dualdiff_amd.networks.unet_addon_rawbox import BEVControlNetModel
     return BEVControlNetModel(block_out_channels=(320, 256, 256, 256), cross_attention_dim=768, layers_per_block=1,
@@ -95,6 +115,11 @@ def test_controlnet_reference_config_names_and_cfg_helpers():
     cn = seeded_init_(small_cnet(), 5)
     assert isinstance(cn.controlnet_cond_embedding, ControlNetConditioningEmbedding)
     assert isinstance(cn.bbox_embedder, ContinuousBBoxWithTextEmbedding)
+    from dualdiff_amd.misc.common import load_module
+    from dualdiff_amd.networks.map_embedder import BEVControlNetConditioningEmbedding
+    from dualdiff_amd.networks.unet_addon_rawbox import _own_path
+    bev = load_module(_own_path("magicdrive.networks.map_embedder.BEVControlNetConditioningEmbedding"))()   # vanilla MagicDrive's
+    assert isinstance(bev, BEVControlNetConditioningEmbedding) and len(bev.blocks) == 6 and bev._geom[-1] == (1, 2)
     assert len(cn.controlnet_down_blocks) == 1 + 3 * 2 + 1
     assert cn.uncond_cam_param([2, 6]).shape == (2, 6, 3, 7)
     assert cn.uncond_cam_param(4).shape == (1, 4, 3, 7)

@@ -1226,11 +1226,13 @@ def test_dma_gemm_conv_concurrent_launches_bitwise(ops):
                                   (12, 4, 7, 2560, 1280, 31, 12), (5, 7, 13, 640, 1280, 12, 3), (3, 14, 25, 320, 640, 31, 2)],
                          ids=lambda c: str(c))
 @pytest.mark.parametrize("silu,want_x", [(True, False), (False, True)])
-def test_conv_splitk_reduce_folded_into_groupnorm(ops, dtype, case, silu, want_x):
+def test_conv_splitk_reduce_folded_into_groupnorm(ops, dtype, case, silu, want_x, monkeypatch):
     """dd_groupnorm_splitk (round 3): the GroupNorm that reads a split-K conv's output adds the slabs, applies the conv's
     epilogue (bias + time vector + residual) and normalises in ONE launch — in place of the reduce launch + GroupNorm.
-    Same arithmetic in the same order: bit-identical to the two-step form (both for y and, when kept, for x)."""
+    Same arithmetic in the same order: bit-identical to the two-step form (both for y and, when kept, for x).  The path
+    is OFF by default (0.5 % slower on the step, ops.GN_SPLITK) and switched on here."""
     from dualdiff_amd.networks.layers import GroupNorm
+    monkeypatch.setattr(ops, "GN_SPLITK", True)
     m, h, w_, cin, cout, tile, split = case
     x = rnd((m * h * w_, cin), dtype, 1)
     w = L.pack_conv_weight(rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5))

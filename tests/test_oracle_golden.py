@@ -41,6 +41,15 @@ def test_cond_embedder():
 
 
 @torch.no_grad()
+def test_bev_map_embedder():
+    """map_embedder.py:10-77 (asymmetric paddings, (2, 1) stride): oracle vs the reference's own output."""
+    m = seeded_init_(R.BEVControlNetConditioningEmbedding(), C.SEED_BEV_EMB)
+    out = m(C.bev_map())
+    assert tuple(out.shape) == (6, 320, 28, 50)
+    C.compare(gold("bev_map_embedder"), "out", out, RTOL, ATOL)
+
+
+@torch.no_grad()
 def test_bbox_embedder():
     m = seeded_init_(R.BBoxEmbedder(), C.SEED_BOX)
     bb, cl, mk = C.box_inputs()

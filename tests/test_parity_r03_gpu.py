@@ -266,6 +266,23 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["outputs_finite"] and out["value"] > 0 and out["scaling"] == "weak"
 
 
+def test_bench_frame_split_two_ranks_on_one_gpu():
+    """SURVEY §8e frame split through bench.py: a 4-frame video over 2 self-launched ranks that share cuda:0; every
+    video block's ST-Attn sources and temporal K|V cross the ranks through parallel.FrameExchange (gloo, host-staged:
+    plumbing, never a measurement).  The line must describe the split and carry the unverified-on-hardware label."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DD_BENCH_SHARE_GPU="1", DD_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "4", "--parallelism", "frame-split", "--single-dtype", "--no-roofline",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["outputs_finite"] and out["value"] > 0 and out["scaling"] == "strong"
+    fs = out["config"]["frame_split"]
+    assert fs["frames_per_rank"] == [2, 2] and fs["verified_on_multi_gpu_hardware"] is False
+    assert fs["rank0_temporal_gathered_bytes_per_forward"] > 0 and out["config"]["hip_graph"] is False
+
+
 # ------------------------------------------------------------------ RCCL view split (>= 2 GPUs) ----
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL device path of HaloExchange)")
 def test_view_split_two_ranks_rccl():

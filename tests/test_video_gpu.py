@@ -105,3 +105,161 @@ def test_video_unet_forward(gpu, dtype):
                   mid_block_additional_residual=mid.cuda().to(dtype)).sample
     rec = []
     assert report("video unet eps (T=2, 6 views)", out, ref, dtype, rec, emul) <= 1.0, rec
+
+
+# ------------------------------------------------------------------ frame split on one GPU ----
+class _LocalFrameExchange:
+    """In-process stand-in for parallel.FrameExchange: the frame shards run as threads of this process (one HIP
+    stream each) and read each other's buffers between two barriers."""
+
+    def __init__(self, plans):
+        import threading
+        self.plans = plans
+        self.barrier = threading.Barrier(len(plans))
+        self.slots = {}
+
+    def bind(self, plan):
+        outer = self
+
+        class Bound:
+            def _swap(self, key, value):
+                torch.cuda.current_stream().synchronize()
+                outer.slots[(key, plan.rank)] = value
+                outer.barrier.wait()
+
+            def _done(self):
+                torch.cuda.current_stream().synchronize()
+                outer.barrier.wait()
+
+            def st_sources(self, first_local, last_local):
+                self._swap("st", (first_local, last_local))
+                first = outer.slots[("st", 0)][0].clone()
+                prev = outer.slots[("st", max(plan.rank - 1, 0))][1 if plan.rank else 0].clone()
+                self._done()
+                return first, prev
+
+            def gather_frames(self, local):
+                self._swap("tmp", local)
+                out = torch.cat([outer.slots[("tmp", p.rank)] for p in outer.plans], dim=0)
+                self._done()
+                return out
+        return Bound()
+
+
+def _run_threads(work, items, ex):
+    import threading
+    errs = []
+
+    def guarded(it):
+        try:
+            with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream()):
+                work(it)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:          # noqa: BLE001  (reported to the main thread)
+            errs.append(e)
+            ex.barrier.abort()
+    torch.cuda.synchronize()
+    ths = [threading.Thread(target=guarded, args=(it,)) for it in items]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("dim,n,frames,scenes,shards", [(640, 350, 4, 2, 2), (1280, 91, 8, 1, 3), (320, 1400, 3, 1, 3)])
+def test_frame_split_video_block_one_gpu(gpu, dim, n, frames, scenes, shards):
+    """One video block with its T frames spread over `shards` virtual ranks (threads on one GPU): ST-Attn fetches
+    frame 0 and the previous frame across the cut, temporal attention runs local queries against the gathered K|V of
+    all frames — the concatenated result reproduces the unsharded block up to the storage rounding (row counts per
+    launch differ, so GEMM tiles do).  Balanced and ragged (8 frames over 3) splits."""
+    from dualdiff_amd.networks.video_blocks import VideoMultiviewTransformerBlock
+    from dualdiff_amd.parallel import FrameShard, FrameSplitPlan
+    from tests.parity_util import log_row, rel_l2
+    dtype, hd = torch.float16, dim // 8
+    ora = V.VideoMultiviewTransformerBlock(dim, 8, hd, cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames)
+    sd = {k: C.bf16_round(v) for k, v in seeded_state_dict(ora, 51).items()}
+    x = C.bf16_round(seeded_tensor((scenes, frames, 6, n, dim), 1)).cuda().to(dtype)
+    ctx = C.bf16_round(seeded_tensor((scenes, frames, 6, 20, 768), 2)).cuda().to(dtype)
+
+    def make():
+        blk = VideoMultiviewTransformerBlock(dim, 8, hd, cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames)
+        blk.load_state_dict(sd, strict=True)
+        return blk.to("cuda", dtype)
+    with torch.no_grad():
+        want = make().run(x.reshape(-1, dim), scenes * frames * 6, n, ctx.reshape(-1, 768), 20) \
+            .reshape(scenes, frames, 6, n, dim).float().cpu()
+    plans = [FrameSplitPlan(shards, r, frames) for r in range(shards)]
+    ex = _LocalFrameExchange(plans)
+    outs = {}
+
+    def work(p):
+        blk = make()
+        blk.frame_shard = FrameShard(p, ex.bind(p))
+        xs, cs = x[:, p.lo:p.hi].contiguous(), ctx[:, p.lo:p.hi].contiguous()
+        m = scenes * p.n_local * 6
+        outs[p.rank] = blk.run(xs.reshape(-1, dim), m, n, cs.reshape(-1, 768), 20) \
+            .reshape(scenes, p.n_local, 6, n, dim).float().cpu()
+    _run_threads(work, plans, ex)
+    got = torch.cat([outs[p.rank] for p in plans], dim=1)
+    e = rel_l2(got, want)
+    print("frame split x%d block C=%d T=%d: vs unsharded rel-L2 %.3e" % (shards, dim, frames, e))
+    log_row("frame split x%d video block C=%d T=%d vs unsharded" % (shards, dim, frames), dtype, e, 0.0, 1e-3)
+    assert e <= 1e-3
+    # the exchange matters: without the other ranks' frames the last shard's result is far off
+    blk = make()
+    blk.n_frames = plans[-1].n_local
+    p = plans[-1]
+    with torch.no_grad():
+        alone = blk.run(x[:, p.lo:p.hi].reshape(-1, dim), scenes * p.n_local * 6, n,
+                        ctx[:, p.lo:p.hi].reshape(-1, 768), 20).reshape(scenes, p.n_local, 6, n, dim).float().cpu()
+    assert rel_l2(alone, want[:, p.lo:p.hi]) > 20 * max(e, 1e-4)
+
+
+def test_frame_split_video_unet_one_gpu(gpu):
+    """Whole video UNet (4 frames x 6 views, full widths, ControlNet residuals) with its frames over 2 virtual ranks
+    vs the unsharded network: every video block exchanges through FrameShard; eps agrees to the storage rounding."""
+    from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiviewVideo
+    from dualdiff_amd.parallel import FrameShard, FrameSplitPlan
+    from tests.parity_util import log_row, rel_l2
+    dtype, frames, shards = torch.float16, 4, 2
+    ora = V.UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames)
+    sd = {k: C.bf16_round(v) for k, v in seeded_state_dict(ora, 61).items()}
+    del ora
+    sample = C.bf16_round(seeded_tensor((frames, 6, 4, C.H, C.W), 1)).cuda().to(dtype)
+    ctx = C.bf16_round(seeded_tensor((frames, 6, 15, 768), 2)).cuda().to(dtype)
+    shapes = [(320, 28, 50)] * 3 + [(320, 14, 25)] + [(640, 14, 25)] * 2 + [(640, 7, 13)] + \
+             [(1280, 7, 13)] * 2 + [(1280, 4, 7)] * 3
+    down = [C.bf16_round(seeded_tensor((frames, 6) + s, 100 + i, 0.3)).cuda().to(dtype) for i, s in enumerate(shapes)]
+    mid = C.bf16_round(seeded_tensor((frames, 6, 1280, 4, 7), 130, 0.3)).cuda().to(dtype)
+
+    def make():
+        net = UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames)
+        net.load_state_dict(sd, strict=True)
+        return net.to("cuda", dtype).eval()
+
+    def fwd(net, lo, hi):
+        f = lambda t: t[lo:hi].reshape((-1,) + tuple(t.shape[2:]))          # noqa: E731
+        return net(f(sample), 481, encoder_hidden_states=f(ctx), down_block_additional_residuals=[f(d) for d in down],
+                   mid_block_additional_residual=f(mid)).sample.float().cpu()
+    with torch.no_grad():
+        want = fwd(make(), 0, frames)
+    plans = [FrameSplitPlan(shards, r, frames) for r in range(shards)]
+    ex = _LocalFrameExchange(plans)
+    nets = [make() for _ in plans]
+    for net, p in zip(nets, plans):
+        net.set_frame_shard(FrameShard(p, ex.bind(p)))
+    outs = {}
+
+    def work(i):
+        outs[i] = fwd(nets[i], plans[i].lo, plans[i].hi)
+    _run_threads(work, list(range(shards)), ex)
+    got = torch.cat([outs[i] for i in range(shards)], dim=0)
+    e = rel_l2(got, want)
+    print("frame split x2 video UNet T=4: eps vs unsharded rel-L2 %.3e" % e)
+    log_row("frame split x2 video unet eps (T=4) vs unsharded", dtype, e, 0.0, 2e-3)
+    assert e <= 2e-3
+    with pytest.raises(ValueError):
+        nets[0].set_frame_shard(FrameShard(FrameSplitPlan(2, 0, 6)))
+    nets[0].set_frame_shard(None)
+    assert all(getattr(m, "frame_shard", None) is None for m in nets[0].modules())
