@@ -404,7 +404,7 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
         for i in range(args.warmup):
             den.step(i % 50)
         barrier()
-        if args.tune_cache and rank == 0 and (args.retune or not os.path.exists(args.tune_cache)):
+        if args.tune_cache and rank == 0 and (args.retune or args.challenge_tiles or not os.path.exists(args.tune_cache)):
             O.save_tuned(args.tune_cache)
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -550,6 +550,9 @@ def main():
     ap.add_argument("--retune", action="store_true",
                     help="ignore the tracked table, time every shape again and write the result to --tune-cache "
                          "(default target: dualdiff_amd/tuned/gfx950.json, merged with its other entries)")
+    ap.add_argument("--challenge-tiles", default="",
+                    help="comma-separated GEMM tile ids added after the tracked table was written: every entry's incumbent is "
+                         "timed against them once (3 %% to win) and the table is written back to --tune-cache")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher / rendezvous check only (gloo, no GPU call, no measurement): prints n_gpus")
     args = ap.parse_args()
@@ -587,6 +590,9 @@ def main():
     from dualdiff_amd import ops as O
     if args.retune:
         O.forget_tuned()
+        args.tune_cache = args.tune_cache or O.TUNE_TABLE_PATH
+    elif args.challenge_tiles:
+        O.CHALLENGE_TILES = tuple(int(t) for t in args.challenge_tiles.split(",") if t.strip())
         args.tune_cache = args.tune_cache or O.TUNE_TABLE_PATH
     elif args.tune_cache and os.path.exists(args.tune_cache):
         O.load_tuned(args.tune_cache)

@@ -37,6 +37,7 @@ class GemmDesc(Structure):
         ("phase", c_int32),
         ("ln_out", c_void_p), ("ld_ln_out", c_int64), ("lno_gamma", c_void_p), ("lno_beta", c_void_p),
         ("splitk_inkernel", c_int32),
+        ("prefetch", c_void_p), ("prefetch_bytes", c_int64),
     ]
 
 

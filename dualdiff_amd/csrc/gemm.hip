@@ -54,6 +54,7 @@ struct GemmParams {
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
   void* ln_out; int64_t ld_ln_out;       // LayerNorm EMITTED by the epilogue of the 80x320 tile (second output)
   const void* lno_gamma; const void* lno_beta;
+  const void* pf_ptr; uint32_t pf_bytes; int pf_blocks;   // weight prefetch carried by spare workgroups (dd_prefetch_block)
 };
 
 // n / d for 0 <= n < 2^22 (host-checked: rows) and the host-side inv = 1.0f / d: (n + 0.5) * inv is never within
@@ -128,6 +129,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
+}
+
+// WEIGHT PREFETCH BY SPARE WORKGROUPS.  A step streams 3.3 GB of weights through the 256 MiB Infinity Cache, so every
+// launch meets its weights cold in HBM (measured: 1092x1280x1280 16.3 us with HBM-cold, 14.2 with Infinity-Cache-resident,
+// 12.4 with L2-resident weights) while HBM idles > 95 % of the time.  A launch whose grid leaves workgroup slots empty
+// (the few-row levels: 80-240 tiles on 256 CUs) carries `pf_blocks` extra workgroups at the END of its grid that only
+// READ the weights of the NEXT weight-bearing launch of the same stream (host: ops._pf_hint) — 16 B per lane, 16 loads
+// in flight — so that launch finds them in the memory-side cache.  No graph node, no stream edge (a prefetch stream
+// inside the captured step cost 4 ms); reads only, so there is nothing to synchronise.
+// MEASURED on the step: not a win at any size (-1.7 % with 32 MB / 96 workgroups, +-0.2 % with 1-2 MB / 8-16); the host
+// side does not pass hints by default (ops.PREFETCH).
+template <int THREADS>
+__device__ __forceinline__ void dd_prefetch_block(const GemmParams& p, int pb) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.pf_ptr), 0, p.pf_bytes, 0x00020000);
+  const uint32_t per = ((p.pf_bytes / (uint32_t)p.pf_blocks) + 15u) & ~15u;
+  const uint32_t beg = (uint32_t)pb * per;
+  const uint32_t end = min(p.pf_bytes, beg + per);
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (uint32_t off = beg + threadIdx.x * 16u; off < end; off += THREADS * 16u * 16u) {
+    u32x4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                 // out-of-range lanes read zeros (buffer bounds) — never past the tensor
+      const uint32_t o = off + (uint32_t)j * THREADS * 16u;
+      v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, o < end ? o : 0xFFFFFFF0u, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc |= v[j];
+  }
+  asm volatile("" ::"v"(acc[0] | acc[1] | acc[2] | acc[3]));     // keeps the loads alive; nothing is stored
 }
 
 // ---- accumulator tile -> global (shared by both kernel families) ---------------------------
@@ -735,6 +765,10 @@ void dd_gemm2_kernel(const GemmParams p) {
   const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   DD_STAMP(0);
+  if (p.pf_blocks && (int)blockIdx.x >= (int)gridDim.x - p.pf_blocks) {        // spare workgroup: prefetch only
+    if (blockIdx.z == 0) dd_prefetch_block<64 * NW>(p, (int)blockIdx.x - ((int)gridDim.x - p.pf_blocks));
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);
 
@@ -1138,6 +1172,10 @@ void dd_conv3s_kernel(const GemmParams p) {
   const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   DD_STAMP(0);
+  if (p.pf_blocks && (int)blockIdx.x >= (int)gridDim.x - p.pf_blocks) {        // spare workgroup: prefetch only
+    if (blockIdx.z == 0) dd_prefetch_block<64 * NW>(p, (int)blockIdx.x - ((int)gridDim.x - p.pf_blocks));
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* abuf = reinterpret_cast<T*>(smem);                 // [2][AROWS][64]
   T* wring = abuf + 2 * AROWS * BK;                     // [NSW][BN][64]
@@ -1822,6 +1860,16 @@ constexpr TileCfg kTiles[] = {
     // 80 WHOLE rows of a 320-wide output per workgroup (1 x 10 waves): the only tile whose epilogue can emit
     // LayerNorm(out) as a second tensor (dd_gemm_desc.ln_out); 16800 rows -> 210 workgroups, one generation
     {40, 1, 10, 5, 2, 2, "80x320/dma2"},
+    // 1092 x 1280 outputs over 256 CUs = 5460 per CU: 96x64 -> 12 x 20 = 240 workgroups (one generation, nearly every
+    // CU busy) staging 410 KB each where the 64x128 tile stages 491 KB on 180 CUs.  Challenged against the tracked table
+    // (bench.py --challenge-tiles 52, cold weights, 3 % to win): takes 28 of the dense shapes per dtype, ~1 us each
+    // (1092x1280x1280 15.4 -> 14.4, 336x1280x1280 14.8 -> 13.8 and no split-K, 4200x640x1920 27.1 -> 21.7); 96x128
+    // tiles won nothing (profiles/r03_tile_challenge.txt)
+    {52, 2, 2, 3, 2, 3, "96x64/dma3"},
+    // 32-row tiles for the few-row GEMMs (time / box / text embeddings: 12-240 rows; 336 x 1280 -> 11 x 20 workgroups):
+    // 1-2 us each in the same challenge; 96x64 with 2 / 4 slots, 96x128 and 192x64 tiles won nothing and were removed
+    {59, 2, 2, 1, 2, 3, "32x64/dma3"},
+    {60, 2, 2, 1, 2, 6, "32x64/dma6"},
     // 192 rows: 1092 rows -> 6 row tiles (180 workgroups at N = 3840 where 256x128 has 150): the per-CU staging rate,
     // not the tile's arithmetic intensity, bounds a launch that leaves CUs without a workgroup (1092x3840x1280:
     // 26.5 -> 23.2 us cold, 1092x1280x6400: 41.4 -> 37.6)
@@ -2033,6 +2081,23 @@ int launch_cfg(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
+// Spare workgroups for the weight prefetch: only when every tile of the launch is resident at once and at least 8 slots
+// stay empty; ~64 KB in flight per 256-thread workgroup, one workgroup per 128 KB of weights, at most 96.
+static int dd_prefetch_blocks(const GemmParams& p, const void* kern, int threads, size_t smem, int blocks,
+                              std::atomic<int>& resident) {
+  if (!p.pf_ptr || !p.pf_bytes || p.persist) return 0;
+  int per_cu = resident.load(std::memory_order_relaxed);
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    resident.store(per_cu, std::memory_order_relaxed);
+  }
+  const int spare = kNumCU * per_cu - blocks;
+  if (spare < 8) return 0;
+  const int want = (int)((p.pf_bytes + (128u << 10) - 1) / (128u << 10)) * 256 / threads;
+  static const int cap = getenv("DD_PF_MAX_BLOCKS") ? atoi(getenv("DD_PF_MAX_BLOCKS")) : 96;
+  return std::max(std::min(8, cap), std::min(std::min(spare, cap), want));
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
 int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -2042,6 +2107,15 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  static std::atomic<int> pf_resident{0};
+  const int pf = dd_prefetch_blocks(p, reinterpret_cast<const void*>(kern), 64 * WM * WN, smem, (int)grid.x * pl.split, pf_resident);
+  if (pf) {                                // spare workgroups at the end of the grid read the next launch's weights
+    GemmParams q = p;
+    q.pf_blocks = pf;
+    grid.x += pf;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, q);
+    return dd_check_launch();
+  }
   if constexpr (!CONV) {
     if (pl.persist_ok) {                 // more tiles than resident workgroups: walk them with the ring running ahead
       static std::atomic<int> resident{0};
@@ -2074,6 +2148,15 @@ int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
+  static std::atomic<int> pf_resident{0};
+  const int pf = dd_prefetch_blocks(p, reinterpret_cast<const void*>(kern), 64 * WM * WN, smem, (int)grid.x * pl.split, pf_resident);
+  if (pf) {
+    GemmParams q = p;
+    q.pf_blocks = pf;
+    grid.x += pf;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, q);
+    return dd_check_launch();
+  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
   return dd_check_launch();
 }
@@ -2156,6 +2239,9 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
     case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
     case 40: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 1, 10, 5, 2, 2, false, false>(p, pl, s); break;
+    case 52: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 3, 2, 3, CONV, false>(p, pl, s); break;
+    case 59: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 2, 2, 1, 2, 3, false, false>(p, pl, s); break;
+    case 60: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 2, 2, 1, 2, 6, false, false>(p, pl, s); break;
     case 50: return launch_cfg2<T, 2, 4, 8, 4, 2, CONV, GEGLU>(p, pl, s);
     case 44: return launch_cfg2<T, 4, 2, 3, 4, 3, CONV, GEGLU>(p, pl, s);
     case 46: return launch_cfg2<T, 4, 2, 3, 4, 2, CONV, GEGLU>(p, pl, s);
@@ -2325,6 +2411,12 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta;
   p.w_scale = reinterpret_cast<const float*>(d->w_scale);
   p.ln_out = d->ln_out; p.ld_ln_out = d->ld_ln_out; p.lno_gamma = d->lno_gamma; p.lno_beta = d->lno_beta;
+  p.pf_ptr = nullptr; p.pf_bytes = 0; p.pf_blocks = 0;
+  if (d->prefetch && d->prefetch_bytes >= (64 << 10) && dd_aligned16(d->prefetch)) {
+    p.pf_ptr = d->prefetch;                                   // the launchers decide whether spare workgroups exist
+    static const int64_t cap_mb = getenv("DD_PF_MAX_MB") ? atoi(getenv("DD_PF_MAX_MB")) : 32;
+    p.pf_bytes = (uint32_t)std::min<int64_t>(d->prefetch_bytes, cap_mb << 20) & ~15u;
+  }
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;

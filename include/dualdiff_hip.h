@@ -172,6 +172,13 @@ typedef struct dd_gemm_desc {
    * order and runs the epilogue — bit-identical to form 0.  Tiles x 4 B must fit the counter region and the slab
    * region must be < 4 GiB, else form 0 is used. */
   int32_t splitk_inkernel;
+  /* WEIGHT PREFETCH HINT (optional; dense DMA tiles and the direct conv only, ignored elsewhere): `prefetch_bytes` bytes
+   * at `prefetch` — the weights of the NEXT weight-bearing launch of this stream — are READ by spare workgroups of this
+   * launch (only when its grid leaves workgroup slots empty), so that they sit in the 256 MiB memory-side cache when
+   * that launch starts (a denoising step streams 3.3 GB of weights: every launch meets its weights cold otherwise).
+   * Nothing is written; the range must stay mapped for the duration of the launch.  NULL / 0 = off. */
+  const void* prefetch;
+  int64_t prefetch_bytes;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);

@@ -49,8 +49,8 @@ def test_gemm_identity_asymmetric(ops):
     check(y, w.float().cpu().t(), torch.float16, "gemm A=I")
 
 
-ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46]
-DMA_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46]     # 29 is GEGLU-only
+ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46, 52, 59, 60]
+DMA_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46, 52]     # 29 is GEGLU-only
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -426,7 +426,7 @@ def test_gemm_geglu_dma_tiles(ops, tile):
     check(y, L.linear_ref(a, w, b, geglu=True), dtype, "geglu dma tile%d" % tile, 2.0)
 
 
-@pytest.mark.parametrize("tile", DMA_TILES)
+@pytest.mark.parametrize("tile", DMA_TILES + [59, 60])          # 59 / 60 (32-row tiles) have no conv form
 def test_gemm_concat_dma_tiles(ops, tile):
     """Two-source A operand (up-path shortcut on [h, skip]) + full epilogue on the DMA family."""
     dtype = torch.float16
@@ -859,7 +859,7 @@ def test_ors_projection_edge_cases():
 
 
 # ------------------------------------------------------------------ persistent tile walk ----
-@pytest.mark.parametrize("tile", [t for t in DMA_TILES if t not in (21, 22)])
+@pytest.mark.parametrize("tile", [t for t in DMA_TILES if t not in (21, 22)] + [59])
 def test_gemm_persistent_walk_dense(ops, tile):
     """More tiles than resident workgroups and a short K loop (the QKV / to_out shapes of the 28x50 level): the
     LDS-DMA family walks several tiles per workgroup with the ring running ahead across the tile boundary
@@ -1254,3 +1254,27 @@ def test_conv_splitk_reduce_folded_into_groupnorm(ops, dtype, case, silu, want_x
     else:
         with pytest.raises(RuntimeError):
             gn.run(out, m, h * w_, silu)              # the cache is consumed once and x was never written
+
+
+# ------------------------------------------------------------------ weight prefetch by spare workgroups ----
+@pytest.mark.parametrize("tile,split", [(52, 1), (14, 1), (13, 3), (59, 1)])
+def test_gemm_prefetch_hint_changes_nothing(ops, tile, split):
+    """dd_gemm_desc.prefetch: spare workgroups at the end of the grid only READ the hinted range (the next launch's
+    weights) — the result is bit-identical with and without the hint, for ranges that are not a multiple of the
+    per-workgroup share — exercised through the Python-side hint chain (ops.PREFETCH, off by default)."""
+    dtype = torch.float16
+    rows, n, k = 1092, 1280, 1280
+    a, w, b = rnd((rows, k), dtype, 1), rnd((n, k), dtype, 2, 0.03), rnd((n,), dtype, 3)
+    nxt = rnd((3 * 1280 * 1280 + 8,), dtype, 4)                     # "next weights": 9.8 MB + a ragged tail
+    ref = ops.gemm(a, w, b, tile=tile, split_k=split)
+    old = ops.PREFETCH
+    try:
+        ops.PREFETCH = True
+        ops._PF_LAST.clear(); ops._PF_NEXT.clear()
+        ops.gemm(a, w, b, tile=tile, split_k=split)                 # records nothing yet (no predecessor)
+        ops.gemm(a, nxt[:1280 * 1280].view(1280, 1280), None, tile=tile, split_k=split)     # chain: w -> nxt
+        y = ops.gemm(a, w, b, tile=tile, split_k=split)             # this launch carries the hint for nxt
+        assert ops._PF_NEXT, "no hint recorded"
+    finally:
+        ops.PREFETCH = old
+    assert torch.equal(y, ref)
