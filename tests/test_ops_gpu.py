@@ -1265,16 +1265,17 @@ def test_gemm_prefetch_hint_changes_nothing(ops, tile, split):
     dtype = torch.float16
     rows, n, k = 1092, 1280, 1280
     a, w, b = rnd((rows, k), dtype, 1), rnd((n, k), dtype, 2, 0.03), rnd((n,), dtype, 3)
-    nxt = rnd((3 * 1280 * 1280 + 8,), dtype, 4)                     # "next weights": 9.8 MB + a ragged tail
+    nxt = rnd((1288, k), dtype, 4, 0.03)                            # the "next" weights: 3.3 MB, not a multiple of the shares
     ref = ops.gemm(a, w, b, tile=tile, split_k=split)
     old = ops.PREFETCH
     try:
         ops.PREFETCH = True
         ops._PF_LAST.clear(); ops._PF_NEXT.clear()
         ops.gemm(a, w, b, tile=tile, split_k=split)                 # records nothing yet (no predecessor)
-        ops.gemm(a, nxt[:1280 * 1280].view(1280, 1280), None, tile=tile, split_k=split)     # chain: w -> nxt
+        ops.gemm(a, nxt, None, tile=tile, split_k=split)            # chain: w -> nxt (both tensors stay alive)
         y = ops.gemm(a, w, b, tile=tile, split_k=split)             # this launch carries the hint for nxt
-        assert ops._PF_NEXT, "no hint recorded"
+        hint = ops._PF_NEXT.get(w.data_ptr())
+        assert hint is not None and hint[0]() is nxt and hint[2] == nxt.numel() * 2, "no hint recorded"
     finally:
         ops.PREFETCH = old
     assert torch.equal(y, ref)
