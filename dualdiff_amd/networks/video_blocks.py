@@ -81,7 +81,7 @@ class VideoMultiviewTransformerBlock(BasicMultiviewTransformerBlock):
                             out=o[rows], seq_strides=(v_n * l * 3 * c, 3 * c), out_seq_strides=(v_n * l * c, c))
             return a.to_out[0].run(o, res=h)
         # frame split: local queries against the K|V rows of ALL frames, gathered frame-major (T, nb, V*l, 2C)
-        kv_loc = qkv[:, c:].reshape(nb, t_n, v_n * l, 2 * c).permute(1, 0, 2, 3).contiguous()
+        kv_loc = qkv.view(nb, t_n, v_n * l, 3 * c)[..., c:].permute(1, 0, 2, 3).contiguous()        # one copy
         kv_all = self.frame_shard.exchange.gather_frames(kv_loc)
         t_all = kv_all.shape[0]
         if t_all != self.n_frames:
