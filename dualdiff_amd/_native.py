@@ -96,6 +96,8 @@ SIGNATURES = {
                                     c_void_p, c_int64, c_void_p]),
     "dd_groupnorm_workspace_bytes": (c_int64, [c_int32, c_int32]),
     "dd_groupnorm_is_fused": (c_int32, [c_int32, c_int32, c_int32]),
+    "dd_groupnorm_is_coop": (c_int32, [c_int32, c_int32, c_int32]),
+    "dd_groupnorm_set_coop": (None, [c_int32]),
     "dd_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                c_int32, c_void_p]),
     "dd_attention": (c_int32, [POINTER(AttnDesc), c_void_p]),

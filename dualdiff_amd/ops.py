@@ -741,9 +741,10 @@ def groupnorm(x, gamma, beta, m, hw, groups, eps, silu, x2=None, out=None):
     _native.check(rc, "groupnorm")
     if e0 is not None:      # HBM-bound: each element read once and written once
         th = lib.dd_groupnorm_is_fused(hw, c1 + c2, groups)
+        coop = not th and lib.dd_groupnorm_is_coop(m, hw, c1 + c2)
         _TIMER.stop(e0, "dd_gn_fused_kernel<%s, %d, 8>" % ("f16" if x.dtype == torch.float16 else "bf16", th) if th
-                    else "dd_gn_stats_kernel + dd_gn_apply_kernel (2 launches)",
-                    0.0, (4.0 if th else 6.0) * out.numel())
+                    else "dd_gn_coop_kernel" if coop else "dd_gn_stats_kernel + dd_gn_apply_kernel (2 launches)",
+                    0.0, (4.0 if th or coop else 6.0) * out.numel())
     return out
 
 

@@ -196,7 +196,11 @@ const char* dd_gemm_kernel_name(const dd_gemm_desc* d);
  * Replaces torch.nn.GroupNorm + SiLU inside ResnetBlock2D (eps 1e-5), the
  * Transformer2DModel input norm (eps 1e-6, no SiLU) and conv_norm_out
  * (networks/unet_2d_condition_multiview.py:519-522).
- * ws: fp32 scratch, >= dd_groupnorm_workspace_bytes(M, G).
+ * ws: fp32 scratch, >= dd_groupnorm_workspace_bytes(M, G), private to the stream.  Its first 256 bytes are the
+ * grid-barrier state of the cooperative single-launch form (dd_gn_coop_kernel: statistics, grid barrier, apply in one
+ * launch for images that do not fit the register-resident form): they must be ZERO before the first call and are not
+ * to be written by anyone else; every launch leaves them ready for the next.  Word 2 is a sticky timeout flag (a
+ * bounded spin instead of a hang if a block never became resident; 0 in every run of this build).
  * C1 + C2 = C, C % G == 0, C1 % 8 == 0, C2 % 8 == 0.
  * ------------------------------------------------------------------------- */
 int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int32_t c2,
@@ -209,6 +213,12 @@ int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups);
  * dd_gn_fused_kernel with that many threads (slab in registers), 0 = dd_gn_stats_kernel + dd_gn_apply_kernel
  * (for profile matching, like dd_gemm_kernel_name). */
 int dd_groupnorm_is_fused(int32_t hw, int32_t c, int32_t groups);
+/* 1 when dd_groupnorm_nhwc takes the cooperative single launch (dd_gn_coop_kernel) for m instances of hw x c — only
+ * asked when dd_groupnorm_is_fused() is 0. */
+int dd_groupnorm_is_coop(int32_t m, int32_t hw, int32_t c);
+/* The cooperative form is OFF by default (measured 2 % slower on the denoising step: blocks that spin at the grid
+ * barrier hold slots other streams' kernels want); 1 turns it on for the process (also: DD_GN_COOP=1). */
+void dd_groupnorm_set_coop(int32_t on);
 
 /* GroupNorm(+SiLU) that CONSUMES the partial slabs of a split-K dd_gemm launched with phase = 1 (in place of that GEMM's
  * reduce launch): x[r, c] = T( sum_z partial[z][r][c] + bias[c] + rowvec[r / hw][c] + res[r][c] ) — exactly what the

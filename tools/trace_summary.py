@@ -15,7 +15,7 @@ lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
 win = rows[lo:hi]
 t0, t1 = win[0][0], max(r[1] for r in win)
 def cls(n):
-    for k in ("conv3s", "gemm2_kernel", "dd_gemm_kernel", "gemm_rp_kernel", "conv3x3_thin", "splitk", "attn", "gn_stats", "gn_apply", "gn_fused", "layernorm", "dd_add", "dd_scale",
+    for k in ("conv3s", "gemm2_kernel", "dd_gemm_kernel", "gemm_rp_kernel", "conv3x3_thin", "splitk", "attn", "gn_stats", "gn_apply", "gn_fused", "gn_coop", "layernorm", "dd_add", "dd_scale",
               "dd_silu", "conv3x3_small", "nchw", "nhwc", "timestep", "cfg_ddim"):
         if k in n:
             if k == "gemm2_kernel":
