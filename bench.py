@@ -370,8 +370,8 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
             raise SystemExit("--parallelism frame-split needs >= 2 ranks and --frames >= ranks")
         from dualdiff_amd.parallel import FrameExchange, FrameShard, FrameSplitPlan
         plan = FrameSplitPlan(world, rank, args.frames)
-        unet.set_frame_shard(FrameShard(plan, FrameExchange(plan)))
-        pairs, local_frames = world, plan.n_local
+        kw = {"frame_shard": FrameShard(plan, FrameExchange(plan))}      # set_inputs() keeps this rank's frames
+        pairs = world
         graph = graph and os.environ.get("DD_VIEW_SPLIT_GRAPH") == "1"     # collectives inside a captured graph: opt-in
         shard_desc = "frames %s" % plan.local
         sent = recv = 0

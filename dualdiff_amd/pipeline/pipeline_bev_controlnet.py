@@ -49,7 +49,7 @@ class BEVDenoiser:
     def __init__(self, unet, controlnets: List, guidance_scale=2.0, num_inference_steps=50,
                  conditioning_scale=1.0, hoist_invariant=False, use_graph=True, use_aug_text=False,
                  parallel_branches=True, cfg_half: Optional[int] = None, cfg_exchange=None,
-                 sampler="ddim", view_shard=None):
+                 sampler="ddim", view_shard=None, frame_shard=None):
         self.unet = unet
         self.controlnets = list(controlnets)
         self.guidance_scale = float(guidance_scale)
@@ -93,6 +93,12 @@ class BEVDenoiser:
         if view_shard is not None:
             unet.set_view_shard(view_shard)
         self.view_shard = view_shard if view_shard is not None else getattr(unet, "view_shard", None)
+        # Frame split (extension): a video UNet whose T frames are spread over ranks
+        # (dualdiff_amd.parallel.FrameShard): set_inputs() takes the inputs of ALL frames — batch entries ordered
+        # scene-major, then frame — and keeps this rank's frame range; adopted from the UNet like the view shard.
+        if frame_shard is not None:
+            unet.set_frame_shard(frame_shard)
+        self.frame_shard = frame_shard if frame_shard is not None else getattr(unet, "frame_shard", None)
 
     # ---------------------------------------------------------------------------- inputs ----
     def set_inputs(self, latents, prompt_embeds, camera_param, bboxes_list, conds):
@@ -103,6 +109,18 @@ class BEVDenoiser:
         if not latents.is_cuda:
             raise RuntimeError("BEVDenoiser runs on the GPU only")
         dt = self.unet.dtype
+        fs = self.frame_shard
+        if fs is not None:                                              # keep this rank's frames of every input
+            t_all = fs.plan.n_frames
+            if latents.shape[0] % t_all:
+                raise ValueError("%d batch entries are not scenes x %d frames" % (latents.shape[0], t_all))
+            sc, n_all = latents.shape[0] // t_all, latents.shape[1]
+            latents = fs.take_frames(latents, sc, 1)
+            prompt_embeds = fs.take_frames(prompt_embeds, 2 * sc, 1)    # [uncond ; cond] x scenes x frames
+            camera_param = fs.take_frames(camera_param, 2 * sc, 1)
+            bboxes_list = [None if d is None else {k: fs.take_frames(v, 2 * sc, 1) for k, v in d.items()}
+                           for d in bboxes_list]
+            conds = [fs.take_frames(cd, 2 * sc, 1 if cd.shape[0] == 2 * sc * t_all else n_all) for cd in conds]
         vs = self.view_shard
         if vs is not None:                                              # keep this rank's views of every input
             n_all = latents.shape[1]
