@@ -366,20 +366,30 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
     if args.parallelism == "frame-split":
         # ONE video (args.scenes scenes x args.frames frames) over all ranks: every rank denoises its frame range with
         # all 6 views local; ST-Attn sources travel p2p, temporal K|V by all-gather, in every video block
-        if dist is None or args.frames < world:
-            raise SystemExit("--parallelism frame-split needs >= 2 ranks and --frames >= ranks")
-        from dualdiff_amd.parallel import FrameExchange, FrameShard, FrameSplitPlan
-        plan = FrameSplitPlan(world, rank, args.frames)
-        kw = {"frame_shard": FrameShard(plan, FrameExchange(plan))}      # set_inputs() keeps this rank's frames
+        if dist is None:
+            raise SystemExit("--parallelism frame-split needs >= 2 ranks")
+        from dualdiff_amd.parallel import FrameExchange, FrameShard, FrameSplitPlan, cfg_all_gather, view_split_groups
+        # from 4 ranks on (even world) the CFG halves are split too: rank = frame shard x 2 + half, the frame exchange
+        # stays inside the half group (ranks of equal parity), the pair {2s, 2s+1} all-gathers the noise prediction
+        cfg_split = world % 2 == 0 and world >= 4
+        halves, pair_groups = view_split_groups(world, cfg_split)
+        shards = world // 2 if cfg_split else world
+        if args.frames < shards:
+            raise SystemExit("--parallelism frame-split: %d frame shards need --frames >= %d" % (shards, shards))
+        plan = FrameSplitPlan(shards, rank // 2 if cfg_split else rank, args.frames)
+        kw = {"frame_shard": FrameShard(plan, FrameExchange(plan, halves[rank % 2 if cfg_split else 0]))}
+        if cfg_split:                                   # set_inputs() keeps this rank's frames, then its CFG half
+            grp = pair_groups[rank // 2]
+            kw.update({"cfg_half": rank % 2, "cfg_exchange": lambda e: cfg_all_gather(e, grp)})
         pairs = world
         graph = graph and os.environ.get("DD_VIEW_SPLIT_GRAPH") == "1"     # collectives inside a captured graph: opt-in
         shard_desc = "frames %s" % plan.local
         sent = recv = 0
         for nblk, (ntok, ch) in ((5, (1400, 320)), (5, (350, 640)), (5, (91, 1280)), (1, (28, 1280))):
-            s_, r_ = plan.message_bytes(ntok, ch, nb=2 * args.scenes)
+            s_, r_ = plan.message_bytes(ntok, ch, nb=(1 if cfg_split else 2) * args.scenes)
             sent, recv = sent + nblk * s_, recv + nblk * r_
         shard_msg = {"rank0_st_attn_sent_bytes_per_forward": sent, "rank0_temporal_gathered_bytes_per_forward": recv,
-                     "exchanges_per_forward": 32, "frames_per_rank": plan.counts()}
+                     "exchanges_per_forward": 32, "frames_per_shard": plan.counts(), "cfg_halves_split": cfg_split}
     den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
                       hoist_invariant=args.hoist_invariant, use_graph=graph,
                       parallel_branches=not args.serial_branches, **kw)
@@ -618,8 +628,9 @@ def main():
            "cfg-split": "CFG halves split over rank pairs x%d (all-gather of the noise prediction per step)" % (world // 2),
            "view-split": "one scene over %d ranks: CFG halves x view shards, p2p neighbour-view K/V exchange per "
                          "transformer block + CFG pair all-gather per step" % world,
-           "frame-split": "one %d-frame video over %d ranks: frame ranges, all views local; ST-Attn sources p2p + "
-                          "temporal K|V all-gather per video block" % (args.frames, world)}[args.parallelism]
+           "frame-split": "one %d-frame video over %d ranks: frame ranges (x CFG halves from 4 ranks on), all views "
+                          "local; ST-Attn sources p2p + temporal K|V all-gather per video block"
+                          % (args.frames, world)}[args.parallelism]
     out = {
         "metric": _metric_name(),
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

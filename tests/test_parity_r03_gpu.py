@@ -279,8 +279,22 @@ def test_bench_frame_split_two_ranks_on_one_gpu():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["outputs_finite"] and out["value"] > 0 and out["scaling"] == "strong"
     fs = out["config"]["frame_split"]
-    assert fs["frames_per_rank"] == [2, 2] and fs["verified_on_multi_gpu_hardware"] is False
+    assert fs["frames_per_shard"] == [2, 2] and fs["verified_on_multi_gpu_hardware"] is False and not fs["cfg_halves_split"]
     assert fs["rank0_temporal_gathered_bytes_per_forward"] > 0 and out["config"]["hip_graph"] is False
+
+
+def test_bench_frame_split_with_cfg_halves_four_ranks_on_one_gpu():
+    """Frame split x CFG split: 4 self-launched ranks on cuda:0 = 2 frame shards x 2 CFG halves of a 4-frame video;
+    the frame exchange runs inside the half groups, the rank pairs all-gather the noise prediction (gloo plumbing)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DD_BENCH_SHARE_GPU="1", DD_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--frames", "4", "--parallelism", "frame-split", "--single-dtype", "--no-roofline",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    fs = out["config"]["frame_split"]
+    assert out["n_gpus"] == 4 and out["outputs_finite"] and fs["frames_per_shard"] == [2, 2] and fs["cfg_halves_split"]
 
 
 # ------------------------------------------------------------------ RCCL view split (>= 2 GPUs) ----
