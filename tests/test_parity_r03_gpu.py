@@ -297,6 +297,26 @@ def test_bench_frame_split_with_cfg_halves_four_ranks_on_one_gpu():
     assert out["n_gpus"] == 4 and out["outputs_finite"] and fs["frames_per_shard"] == [2, 2] and fs["cfg_halves_split"]
 
 
+def test_bench_challenge_tiles_writes_a_loadable_table(tmp_path):
+    """`bench.py --challenge-tiles` (how the 96x64 / 32x64 tiles entered the tracked table): every entry's incumbent is
+    timed against the challengers once and the merged table is written to --tune-cache; the file loads back and still
+    covers the step's shapes.  (Challenging with a tile that is already the incumbent must change nothing.)"""
+    import ast
+    cache = str(tmp_path / "table.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--challenge-tiles", "52", "--tune-cache", cache,
+                        "--steps", "1", "--warmup", "1", "--single-dtype", "--no-roofline", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    blob = json.load(open(cache))
+    assert blob["arch"] == "gfx950" and len(blob["entries"]) >= 100
+    keys = {ast.literal_eval(k) for k, _ in blob["entries"]}
+    assert ("g", 1092, 1280, 1280, 0, 0, False, False) in keys
+    tracked = {k: v for k, v in json.load(open(os.path.join(ROOT, "dualdiff_amd", "tuned", "gfx950.json")))["entries"]}
+    changed = [k for k, v in blob["entries"] if k in tracked and tracked[k][0] == 52 and v[0] != 52]
+    assert not changed, changed          # an incumbent cannot lose to itself
+
+
 # ------------------------------------------------------------------ RCCL view split (>= 2 GPUs) ----
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL device path of HaloExchange)")
 def test_view_split_two_ranks_rccl():
