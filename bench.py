@@ -411,27 +411,33 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # Runtime settle (part of set-up, like the capture itself; reported as config.graph_settle_replays): the first
-        # ~160 replays of a freshly captured graph run 5-6 % slower than all later ones — a COUNT-based effect of the HIP
-        # runtime (the same 160 replays whether a step takes 11 or 19 ms, and whether or not the GPU idled first:
-        # profiles/r03_replay_ramp.txt), not a clock ramp.  A sampler passes it within its first four images; the
-        # benchmark's K timed steps are taken after it, and after the W warm-up steps the contract asks for.
-        if graph:
-            for i in range(args.settle):
-                den.step(i % 50)
+        # A run longer than one 50-step sample starts every new sample from the initial noise again (one 67 k-element copy
+        # per 50 steps): the random-init network is not a denoiser, and fp16 latents pushed through it a few hundred times
+        # overflow — after which every activation is NaN and the step runs 5 % FASTER (less switching power), a number
+        # that means nothing (profiles/r03_nan_speedup.txt).  The reported line also says whether the outputs are finite.
+        lat0 = den.lat2.clone()
+
+        def run_step(k):
+            if k % 50 == 0 and k > 0:
+                den.lat2.copy_(lat0)
+            den.step(k % 50)
+
         for i in range(args.warmup):
-            den.step(i % 50)
+            run_step(i)
         barrier()
         if args.tune_cache and rank == 0 and (args.retune or args.challenge_tiles or not os.path.exists(args.tune_cache)):
             O.save_tuned(args.tune_cache)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            den.step((args.warmup + i) % 50)
+            run_step(args.warmup + i)
         barrier()
         elapsed = time.perf_counter() - t0
         from dualdiff_amd.parallel import max_over_ranks
         elapsed = max_over_ranks(elapsed, device if backend == "nccl" else None)   # slowest rank sets the job's wall time
         finite = bool(torch.isfinite(den.latents.float()).all().item())
+        if not finite and rank == 0:
+            print("[bench] WARNING: non-finite latents after the timed steps (%s) — NaN data runs ~5 %% faster than real "
+                  "data; this measurement is INVALID" % dtype_name, file=sys.stderr)
 
         roofline = None
         if rank == 0 and want_roofline:
@@ -533,8 +539,6 @@ def main():
                          "makes this process the launcher of N child ranks")
     ap.add_argument("--steps", type=int, default=50, help="timed denoising steps (default: one 50-step DDIM sample)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--settle", type=int, default=200,
-                    help="untimed graph replays before the warm-up steps (HIP-graph replay settles after ~160 launches; 0: off)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
                     help="storage / MFMA input type of the headline number (fp32 accumulation either way).  fp16 is "
                          "the reference's eval dtype and what BASELINE.json's metric string names; the other 16-bit "
@@ -658,7 +662,6 @@ def main():
                    "extensions": {"frames_per_scene": args.frames, "fp8": args.fp8_weights,
                                   "lora_rank_folded": args.lora_rank},
                    "hip_graph": res["graph"], "streams": 1 if args.serial_branches else 3,
-                   "graph_settle_replays": args.settle if res["graph"] else 0,
                    "invariant_conditioning": "hoisted" if args.hoist_invariant else "recomputed every step",
                    "algorithmic_tflop_per_step": step_tflop,
                    "algorithmic_tflop_counting": "as the reference WRITES the step (SURVEY §8d: attn4 projects K/V once per "
