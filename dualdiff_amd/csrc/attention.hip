@@ -22,6 +22,12 @@
 #define DD_EXP2(x) (x)
 #else
 #define DD_EXP2(x) __builtin_amdgcn_exp2f(x)
+// max of 8 scores as three v_max3_f32 + one v_max_f32 (a balanced fmaxf tree compiles to seven v_max_f32: the d = 40 loop is
+// VALU-issue-bound and this is 9 instructions of ~70 per 32-key chunk)
+__device__ __forceinline__ float dd_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float dd_max8(const float (&s)[8]) {
+  return fmaxf(dd_max3(dd_max3(s[0], s[1], s[2]), dd_max3(s[3], s[4], s[5]), s[6]), s[7]);
+}
 #endif
 
 namespace {
@@ -211,8 +217,7 @@ void dd_attn_kernel(const AttnParams p) {
         // exact in floating point up to the usual rounding).  The cross-lane max over the four key
         // groups (two ds_bpermute round trips on the critical path) is therefore only taken inside
         // the rare branch; the common case needs a compare and a wave-wide `any`.
-        const float mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
-                                 fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        const float mx_l = dd_max8(s);
         if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {   // wave-uniform, rare after the first tiles
           float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -517,8 +522,7 @@ void dd_attn5_kernel(const AttnParams p) {
               if (t * 16 + r >= rem) s[t * 4 + r] = -INFINITY;
         };
         if (!ONES && tail) mask_tail();
-        float mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
-                           fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        float mx_l = dd_max8(s);
         V8 pv;
         if constexpr (PRE) {
           // s is already (score - m_run) in log2 units.  The very first chunk of a row always takes the
@@ -527,8 +531,7 @@ void dd_attn5_kernel(const AttnParams p) {
           if (first || __any(mx_l > RESCALE_THR)) {
             if (ONES && tail) {
               mask_tail();
-              mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
-                           fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+              mx_l = dd_max8(s);
             }
             float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -558,8 +561,7 @@ void dd_attn5_kernel(const AttnParams p) {
           if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {
             if (ONES && tail) {          // the padded keys scored 0: keep them out of the running max
               mask_tail();
-              mx_l = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])),
-                           fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+              mx_l = dd_max8(s);
             }
             float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
