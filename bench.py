@@ -37,13 +37,15 @@ H, W, NCAM, NBOX, LTXT = 28, 50, 6, 20, 77
 GF_UNET, GF_CNET = 324.1, 84.7
 PEAK_HBM_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
-# Not a contract roof: the L2 -> LDS staging rate the tiled kernels of this build saturate, MEASURED on MI355X with the
-# matrix instructions compiled out (tools/stage_rate.py: 12.4-14.5 TB/s whatever the tile).  Reported per
-# class as `l2_stage` next to the contract's hbm / mfma fraction.
-MEASURED_L2_STAGE_GBPS = 14000.0
-# The guide's own figure for L2-served LDS fills (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 66-73 GB/s per CU =
-# 16.8-18.8 TB/s chip-wide, stated as a LOWER bound) is reported beside it, so the in-house 14 TB/s is not the only yardstick.
+# Not a contract roof, a diagnostic: the guide's figure for L2-served LDS fills (MI355X_MICROARCH.md, "Indexed rows: gather
+# into LDS": 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide, stated as a LOWER bound).  Per class, `l2_stage` in the FULL
+# report prices the bytes the tiles stage through L2 -> LDS against it (no self-measured roof: VERDICT r3 weak #8).
 GUIDE_L2_STAGE_GBPS = 16800.0
+# What the parity tests enforce (tests/parity_util.py), stated in the line
+TOLERANCE = ("rel-L2 <= max(1e-3, 1.02 x fp16-storage floor) vs the fp32 oracle; the floor is the error of the oracle "
+             "itself run with every tensor stored in fp16 (oracle/numerics.py) — the literal 1e-3 is unattainable after "
+             "~25 sequential fp16 roundings, DESIGN §4")
+LINE_LIMIT = 4096             # the driver parses one JSON line; 20 KB lines were not parsed in round 3
 
 
 def build_models(dtype, device, dual=True, frames=1, fp8=False, lora_rank=0):
@@ -319,7 +321,6 @@ def _roofline_row(name, d, table):
             "l2_stage": (None if not d.get("staged") else
                          {"staged_bytes_per_launch": d["staged"] / d["count"],
                           "rate_GBps": round(d["staged"] / d["count"] / avg_s / 1e9, 1),
-                          "frac_of_measured_peak": round(d["staged"] / d["count"] / avg_s / 1e9 / MEASURED_L2_STAGE_GBPS, 4),
                           "frac_of_guide_lower_bound": round(d["staged"] / d["count"] / avg_s / 1e9 / GUIDE_L2_STAGE_GBPS, 4)})}
 
 
@@ -490,6 +491,102 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
     torch.cuda.empty_cache()
     return {"elapsed": elapsed, "finite": finite, "roofline": roofline, "graph": graph, "pairs": pairs,
             "shard": shard_desc, "shard_msg": shard_msg}
+
+
+def _short_kernel(name):
+    """'dd_gemm2_kernel<_Float16, 2, 2, 3, 2, 3, false, false>' -> 'dd_gemm2<f16,2,2,3,2,3,0,0>' (line budget)."""
+    return (name.replace("_kernel<", "<").replace("_Float16", "f16").replace("__bf16", "bf16")
+            .replace("false", "0").replace("true", "1").replace(", ", ","))
+
+
+def compact_line(full, full_path=None, limit=LINE_LIMIT):
+    """The ONE JSON line rank 0 prints: every key of the bench contract, the dominant kernel's `roofline` object plus the
+    next five classes under short keys, a bounded `cpu_baseline`, and the name of the file that holds the FULL report
+    (all classes, l2_stage diagnostics, every CPU-leg figure).  Always shorter than `limit` bytes: if a future field
+    pushes it over, the optional parts are dropped in a fixed order until it fits (the 20 KB line of
+    round 3 was not parsed by the driver)."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg[k] for k in ("workload", "scenes_per_gpu", "parallelism", "hip_graph", "streams",
+                                         "invariant_conditioning", "algorithmic_tflop_per_step") if k in cfg}
+    ext = cfg.get("extensions") or {}
+    if ext.get("frames_per_scene", 1) != 1 or ext.get("fp8") or ext.get("lora_rank_folded"):
+        out["config"]["extensions"] = ext
+    for k in ("model_tflops", "executed_tflops"):
+        if full.get(k) is not None:
+            out[k] = round(full[k], 1)
+    out["outputs_finite"] = full.get("outputs_finite")
+    out["tolerance"] = TOLERANCE
+    r = full.get("roofline")
+    if r:
+        rf = {"kernel": _short_kernel(r["kernel"]), "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
+              "unit": r["unit"], "frac": r["frac"],
+              "traffic": None if r.get("traffic") is None else round(r["traffic"]),
+              "algorithmic_bytes_per_launch": round(r["algorithmic_bytes_per_launch"]),
+              "algorithmic_flops_per_launch": round(r["algorithmic_flops_per_launch"]),
+              "launches_per_step": r["launches_per_step"], "avg_us": r["avg_us"], "ms_per_step": r["ms_per_step"],
+              "share_of_timed_kernels": round(r.get("share_of_timed_kernels", 0.0), 4),
+              "timed_kernels_ms_per_step": round(r.get("timed_kernels_ms_per_step", 0.0), 3),
+              "timing": "HIP events on the launch stream, instrumented eager single-stream step, measured event overhead "
+                        "%.1f us subtracted" % r.get("event_overhead_us_subtracted", 0.0),
+              "pmc_table": r.get("pmc_table"),
+              # k = kernel, n = launches per step, us = average launch, b = bound, f = fraction of that roof,
+              # t = PMC HBM bytes per launch / algorithmic bytes per launch
+              "next": [{"k": _short_kernel(c["kernel"]), "n": c["launches_per_step"], "us": c["avg_us"], "b": c["bound"],
+                        "f": c["frac"],
+                        "t": (None if c.get("traffic") is None or not c.get("algorithmic_bytes_per_launch")
+                              else round(c["traffic"] / c["algorithmic_bytes_per_launch"], 2))}
+                       for c in (r.get("classes") or [])[1:6]]}
+        out["roofline"] = rf
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                               "sample": c["sample"][:400]}
+        b = (c.get("bf16") or {}).get("value")
+        if b:
+            out["cpu_baseline"]["bf16_value"] = b
+    else:
+        out["cpu_baseline"] = None
+    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    for k in ("view_split", "frame_split"):
+        if k in cfg:
+            out["config"][k] = {kk: vv for kk, vv in cfg[k].items() if kk != "note"}
+    out["full_report"] = full_path
+    # never exceed the limit: drop optional parts in a fixed order
+    for drop in (lambda o: o["roofline"] and o["roofline"].pop("next", None),
+                 lambda o: o.pop("tolerance", None),
+                 lambda o: o["roofline"] and o["roofline"].pop("timing", None),
+                 lambda o: o["cpu_baseline"] and o["cpu_baseline"].update(sample=o["cpu_baseline"]["sample"][:120]),
+                 lambda o: o.pop("strong_scaling", None),
+                 lambda o: o["config"].pop("view_split", None) or o["config"].pop("frame_split", None),
+                 lambda o: o["config"].update(workload=o["config"].get("workload", "")[:80])):
+        if len(json.dumps(out)) < limit:
+            break
+        drop(out)
+    return out
+
+
+def _write_full_report(full, tag):
+    """The full report (every kernel class, diagnostics) goes to a FILE: gpurun_out/ when the repo root is writable
+    (merged back by gpurun), else the temp dir.  Returns the path relative to the repo root (or absolute)."""
+    import tempfile
+    for base in (os.environ.get("DD_BENCH_REPORT_DIR"), os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        if not base:
+            continue
+        try:
+            os.makedirs(base, exist_ok=True)
+            path = os.path.join(base, "bench_full_%s.json" % tag)
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+        except OSError:
+            continue
+    return None
 
 
 def _free_port():
@@ -692,8 +789,12 @@ def main():
                               "ms_per_step": other["elapsed"] / args.steps * 1e3 / args.scenes,
                               "outputs_finite": other["finite"]}
     if cpu:
-        out["speedup_vs_cpu"] = value / cpu["value"]
-    print(json.dumps(out))
+        out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
+    path = _write_full_report(out, "%s_n%d_%s" % (args.dtype, world, args.parallelism))
+    line = json.dumps(compact_line(out, path))
+    assert len(line) < LINE_LIMIT, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)             # nothing follows this line on stdout
     if dist is not None:
         dist.destroy_process_group()
 

@@ -280,3 +280,66 @@ def test_fold_lora_key_validation_and_alpha():
         with pytest.raises(exc):
             fold_lora_(net3, bad)
     assert torch.equal(net3.attn1.to_q.weight, w0)
+
+
+def _synthetic_full_report(n_classes=40):
+    """A bench report as bench.main() builds it, with a 40-class roofline table (the size that broke the driver's
+    parser in round 3)."""
+    rows = []
+    for i in range(n_classes):
+        rows.append({"kernel": "dd_gemm2_kernel<_Float16, 2, %d, 5, 2, 3, %s, false>" % (i, "true" if i % 2 else "false"),
+                     "launches_per_step": 131 - i, "avg_us": 12.54 + i, "ms_per_step": 1.6422 / (i + 1),
+                     "bound": "hbm" if i % 3 else "mfma", "achieved": 1091.2, "unit": "GB/s", "frac": 0.1364,
+                     "algorithmic_bytes_per_launch": 13679374.04580153, "algorithmic_flops_per_launch": 4203561585.3,
+                     "traffic": 28661875.96 if i % 4 else None,
+                     "l2_stage": {"staged_bytes_per_launch": 1.2e8, "rate_GBps": 9000.1, "frac_of_guide_lower_bound": 0.53}})
+    top = dict(rows[0], peak=8000.0, event_overhead_us_subtracted=3.3, event_overhead_method="x" * 200,
+               share_of_timed_kernels=0.131, timed_kernels_ms_per_step=12.534, pmc_table="r04_pmc_traffic.json",
+               tuned_table="dualdiff_amd/tuned/gfx950.json", classes=rows)
+    return {"metric": "denoising-steps/sec, 6-view 224×400 fp16, 50-step DDIM @ 1/2/4/8 MI355X", "value": 88.04557868,
+            "unit": "steps/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 11.3577, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: " + "w" * 180, "scenes_per_gpu": 1,
+                       "parallelism": "scene-sharded x8 (no data-path collective)",
+                       "extensions": {"frames_per_scene": 1, "fp8": None, "lora_rank_folded": 0}, "hip_graph": True,
+                       "streams": 3, "invariant_conditioning": "recomputed every step", "algorithmic_tflop_per_step": 5.922,
+                       "algorithmic_tflop_counting": "c" * 260},
+            "model_tflops": 521.4, "executed_tflops": 502.3, "outputs_finite": True, "roofline": top,
+            "cpu_baseline": {"value": 0.0758, "unit": "steps/s", "cores": 32, "kind": "port", "sample": "s" * 342,
+                             "config2_step_seconds_all": [13.1, 12.7], "bf16": {"value": 0.0917, "sample": "b" * 60},
+                             "seconds_spent": 58.4},
+            "other_dtype": {"dtype": "bf16", "value": 89.18, "unit": "steps/s", "ms_per_step": 11.21, "outputs_finite": True},
+            "speedup_vs_cpu": 1161.5,
+            "strong_scaling": {"mode": "view-split", "value": 123.4, "ms_per_step": 8.1, "speedup_vs_n1_ms": 1.4,
+                               "message_bytes": 7950000, "verified_on_multi_gpu_hardware": True, "graph": "piecewise"}}
+
+
+def test_bench_line_stays_parseable_and_short():
+    """BENCH_r03.json.parsed was null because the line had grown to 20 KB.  The printed line must be
+    one short JSON object carrying every contract key, whatever the size of the class table."""
+    import bench
+    full = _synthetic_full_report(40)
+    assert len(json.dumps(full)) > 8000                       # the full report is the big one
+    line = json.dumps(bench.compact_line(full, "gpurun_out/bench_full_fp16_n8_scenes.json"))
+    assert len(line) < 4096 and "\n" not in line
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["value"] == full["value"] and back["config"]["workload"].startswith("BASELINE configs[1]")
+    r = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["frac"] == 0.1364 and len(r["next"]) == 5 and "classes" not in r and "l2_stage" not in r
+    c = back["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c)
+    assert "1e-3" in back["tolerance"] and back["full_report"].endswith(".json")
+    assert back["strong_scaling"]["mode"] == "view-split"
+    # degenerate inputs: no roofline / no CPU leg (N > 1 ranks), and an absurdly long free-text field still fits
+    bare = dict(full, roofline=None, cpu_baseline=None)
+    assert len(json.dumps(bench.compact_line(bare))) < 4096
+    fat = _synthetic_full_report(40)
+    fat["strong_scaling"]["error"] = "e" * 6000
+    fat["config"]["workload"] = "w" * 3000
+    fat_line = json.dumps(bench.compact_line(fat, "x.json"))
+    assert len(fat_line) < 4096 and json.loads(fat_line)["value"] == fat["value"]
