@@ -84,6 +84,7 @@ class Gemm8Desc(Structure):
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "dd_abi_version": (c_int32, []),
+    "dd_desc_size": (c_int64, [c_int32]),
     "dd_error_string": (c_char_p, [c_int32]),
     "dd_target_arch": (c_char_p, []),
     "dd_gemm": (c_int32, [POINTER(GemmDesc), c_void_p]),
@@ -132,6 +133,7 @@ SIGNATURES = {
                                    c_int64, c_int32, c_void_p]),
 }
 
+ABI_VERSION = 2
 _LIB = None
 
 
@@ -160,13 +162,22 @@ def load(build_if_missing=True):
             raise RuntimeError("dualdiff_amd: %s does not export %s" % (path, name))
         fn.restype = res
         fn.argtypes = args
-    if lib.dd_abi_version() != 1:
-        raise RuntimeError("dualdiff_amd: ABI version mismatch")
+    if lib.dd_abi_version() != ABI_VERSION:
+        raise RuntimeError("dualdiff_amd: %s has ABI version %d, this binding needs %d (rebuild: __graft_entry__.build())"
+                           % (path, lib.dd_abi_version(), ABI_VERSION))
+    for which, st in enumerate((GemmDesc, AttnDesc, XAttnDesc, Gemm8Desc)):
+        if lib.dd_desc_size(which) != ctypes.sizeof(st):      # a stale library would read past (or ignore) our fields
+            raise RuntimeError("dualdiff_amd: %s was built with a different %s (%d bytes, binding has %d)"
+                               % (path, st.__name__, lib.dd_desc_size(which), ctypes.sizeof(st)))
     _LIB = lib
     return lib
+
+
+class Unsupported(RuntimeError):
+    """DD_ERR_UNSUPPORTED (-2): the library validated the call and launched NOTHING — the caller may take another form."""
 
 
 def check(rc, what):
     if rc != 0:
         msg = load().dd_error_string(rc).decode()
-        raise RuntimeError("dualdiff_amd.%s failed: %s (%d)" % (what, msg, rc))
+        raise (Unsupported if rc == -2 else RuntimeError)("dualdiff_amd.%s failed: %s (%d)" % (what, msg, rc))

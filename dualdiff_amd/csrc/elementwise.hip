@@ -646,6 +646,15 @@ extern "C" int dd_probe_spin(uint64_t* stamps, uint32_t ticks_100mhz, dd_stream_
 }
 
 extern "C" int dd_abi_version(void) { return DD_ABI_VERSION; }
+extern "C" int64_t dd_desc_size(int which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(dd_gemm_desc);
+    case 1: return (int64_t)sizeof(dd_attn_desc);
+    case 2: return (int64_t)sizeof(dd_xattn_desc);
+    case 3: return (int64_t)sizeof(dd_gemm8_desc);
+  }
+  return -1;
+}
 extern "C" const char* dd_target_arch(void) { return "gfx950"; }
 extern "C" const char* dd_error_string(int code) {
   switch (code) {

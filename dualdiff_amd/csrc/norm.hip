@@ -360,6 +360,10 @@ void dd_gn_coop_kernel(const GnParams p, unsigned* bar) {
     }
   }
   __syncthreads();
+  // A block that gave up waiting must not normalise with incomplete sums: every block re-reads the flag
+  // and, when it is set, writes NaN over its piece — a wrong launch is LOUD (bench.py's outputs_finite, every parity
+  // test) instead of silently off.  ops.groupnorm also checks bar[2] outside capture.
+  const bool gn_timed_out = __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   {
     // combine the per-split partial sums of this instance: chunk-strided sc1 loads, then one thread per group adds
     // the chunk sums in a fixed order (bit-reproducible)
@@ -408,7 +412,7 @@ void dd_gn_coop_kernel(const GnParams p, unsigned* bar) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float y = f[e] * sc[e] + sh[e];
-        f[e] = p.silu ? dd_silu_f(y) : y;
+        f[e] = gn_timed_out ? __builtin_nanf("") : (p.silu ? dd_silu_f(y) : y);
       }
       dd_st16(reinterpret_cast<T*>(p.y) + ((int64_t)inst * p.hw + px) * p.c + ch, dd_pack8<T>(f));
     }

@@ -25,11 +25,12 @@ def lora_keys(model, rank=4, cross_attention_dim=None):
     return out
 
 
-def fold_lora_(model, lora_state_dict, scale=1.0):
+def fold_lora_(model, lora_state_dict, scale=1.0, network_alphas=None):
     """Adds scale * (alpha / rank) * up @ down to the matching projection weights of `model` in place (fp32
     arithmetic, result rounded to the parameter dtype) and drops the packed-weight caches.  `alpha` comes from an
     optional `<...>_lora.alpha` (or `.network_alpha`) entry next to the down / up pair — diffusers / PEFT
-    `network_alpha` — and defaults to the rank (factor 1).  Malformed keys, a missing up-weight, mismatched ranks or
+    `network_alpha` — or from the separate `network_alphas` mapping ({<stem> or <down key>: alpha}, the form diffusers'
+    loaders hand over) and defaults to the rank (factor 1).  Malformed keys, a missing up-weight, mismatched ranks or
     shapes raise with the offending key; entries that are not LoRA matrices are rejected rather than ignored.
     Returns the number of folded matrices."""
     mods = {name: mod for name, mod in model.named_modules() if isinstance(mod, Attention)}
@@ -44,30 +45,33 @@ def fold_lora_(model, lora_state_dict, scale=1.0):
         raise KeyError("LoRA up-weights without a down-weight: %s" % ups[:4])
     plan = []                                # validate EVERYTHING first: a bad entry must not leave a half-folded model
     for key, down in lora_state_dict.items():
-        if True:
-            if not key.endswith(suffix_down):
-                continue
-            stem = key[: -len(suffix_down)]
-            if ".processor." not in stem:
-                raise KeyError("LoRA key %s: expected '<attention path>.processor.<proj>_lora.down.weight'" % key)
-            path, proj = stem.rsplit(".processor.", 1)
-            if proj not in ("to_q", "to_k", "to_v", "to_out"):
-                raise KeyError("LoRA key %s: unknown projection '%s'" % (key, proj))
-            up_key = stem + "_lora.up.weight"
-            if up_key not in lora_state_dict:
-                raise KeyError("LoRA key %s has no matching %s" % (key, up_key))
-            up = lora_state_dict[up_key]
-            attn = mods.get(path)
-            if attn is None:
-                raise KeyError("LoRA key %s names no attention layer of the model" % key)
-            lin = attn.to_out[0] if proj == "to_out" else getattr(attn, proj)
-            rank = down.shape[0]
-            if down.dim() != 2 or up.dim() != 2 or up.shape[1] != rank or down.shape[1] != lin.in_features \
-                    or up.shape[0] != lin.out_features:
-                raise ValueError("LoRA %s: down %s / up %s do not fit a %d -> %d projection"
-                                 % (stem, tuple(down.shape), tuple(up.shape), lin.in_features, lin.out_features))
-            alpha = lora_state_dict.get(stem + "_lora.alpha", lora_state_dict.get(stem + "_lora.network_alpha"))
-            plan.append((attn, lin, down, up, float(scale) * (float(alpha) / rank if alpha is not None else 1.0)))
+        if not key.endswith(suffix_down):
+            continue
+        stem = key[: -len(suffix_down)]
+        if ".processor." not in stem:
+            raise KeyError("LoRA key %s: expected '<attention path>.processor.<proj>_lora.down.weight'" % key)
+        path, proj = stem.rsplit(".processor.", 1)
+        if proj not in ("to_q", "to_k", "to_v", "to_out"):
+            raise KeyError("LoRA key %s: unknown projection '%s'" % (key, proj))
+        up_key = stem + "_lora.up.weight"
+        if up_key not in lora_state_dict:
+            raise KeyError("LoRA key %s has no matching %s" % (key, up_key))
+        up = lora_state_dict[up_key]
+        attn = mods.get(path)
+        if attn is None:
+            raise KeyError("LoRA key %s names no attention layer of the model" % key)
+        lin = attn.to_out[0] if proj == "to_out" else getattr(attn, proj)
+        if down.dim() != 2 or up.dim() != 2 or up.shape[1] != down.shape[0] or down.shape[1] != lin.in_features \
+                or up.shape[0] != lin.out_features:
+            raise ValueError("LoRA %s: down %s / up %s do not fit a %d -> %d projection"
+                             % (stem, tuple(down.shape), tuple(up.shape), lin.in_features, lin.out_features))
+        rank = down.shape[0]
+        # alpha key convention: `<stem>_lora.alpha` or `<stem>_lora.network_alpha` beside the down / up pair (a 0-d or
+        # 1-element tensor, or a number); a separate mapping goes through `network_alphas`
+        alpha = lora_state_dict.get(stem + "_lora.alpha", lora_state_dict.get(stem + "_lora.network_alpha"))
+        if alpha is None and network_alphas:
+            alpha = network_alphas.get(stem, network_alphas.get(stem + "_lora.down.weight"))
+        plan.append((attn, lin, down, up, float(scale) * (float(alpha) / rank if alpha is not None else 1.0)))
     n = 0
     with torch.no_grad():
         for attn, lin, down, up, factor in plan:

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops as O
+from .._native import Unsupported
 from . import layers
 from .layers import Attention, BasicTransformerBlock, LayerNorm, Linear, want_ln_stats
 
@@ -30,13 +31,23 @@ ATTN4_PAIR = __import__("os").environ.get("DD_ATTN4_PAIR", "1") != "0"
 
 
 def _neighbour_sum(q, k, v, batch, l, heads, dim_head, scale, maps, prescaled):
-    """sum_j Attn(q, kv[maps[j]]) (blocks.py:203-217): pairs of neighbours per launch, a single one accumulates."""
+    """sum_j Attn(q, kv[maps[j]]) (blocks.py:203-217): pairs of neighbours per launch, a single one accumulates.  The
+    library refuses the pair form (DD_ERR_UNSUPPORTED, nothing launched) where its 32-bit buffer offsets do not fit or
+    another kernel variant is forced; those calls take the two-launch accumulate form."""
     o, j = None, 0
     while j < len(maps):
         pair = ATTN4_PAIR and j + 1 < len(maps)
-        o = O.attention(q, k, v, batch, l, l, heads, dim_head, scale, kv_batch_map=maps[j],
-                        kv_batch_map2=maps[j + 1] if pair else None, out=o, accumulate=j > 0, q_prescaled=prescaled)
-        j += 2 if pair else 1
+        if pair:
+            try:
+                o = O.attention(q, k, v, batch, l, l, heads, dim_head, scale, kv_batch_map=maps[j],
+                                kv_batch_map2=maps[j + 1], out=o, accumulate=j > 0, q_prescaled=prescaled)
+                j += 2
+                continue
+            except Unsupported:
+                pass
+        o = O.attention(q, k, v, batch, l, l, heads, dim_head, scale, kv_batch_map=maps[j], out=o, accumulate=j > 0,
+                        q_prescaled=prescaled)
+        j += 1
     return o
 
 

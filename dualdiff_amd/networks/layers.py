@@ -78,6 +78,14 @@ class Linear(_Cached):
             self.__dict__["_pk_w"] = _pad_cols(self.weight.detach().reshape(self.out_features, -1))
         return self.__dict__["_pk_w"]
 
+    @property
+    def wx(self):
+        """The (320, 320) weight in the layout dd_xattn320 streams (ops.xattn_pack_weight), packed lazily like w2d and
+        owned by this module."""
+        if "_pk_wx" not in self.__dict__:
+            self.__dict__["_pk_wx"] = O.xattn_pack_weight(self.w2d)
+        return self.__dict__["_pk_wx"]
+
     fp8 = False        # extension (BASELINE configs[4]): multiply by e4m3fn weights + per-channel scales
     fp8_mfma = False   # extension: W8A8 on the fp8 matrix path (dd_gemm8) where it pays: K >= 640 and a wide output
 
@@ -569,13 +577,13 @@ class Attention(_Cached):
                     kv.record_stream(torch.cuda.current_stream())
         if kv is None:
             kv = self.project_kv(ctx2d)
-        if XATTN_FUSED and O.xattn320_ok(c, self.heads, lk) and self.to_q.in_features == c and self.to_q.bias is None \
+        if XATTN_FUSED and O.xattn320_ok(c, self.heads, lk, x2d.shape[0]) and self.to_q.in_features == c and self.to_q.bias is None \
                 and not self.fp8 and not ln_stats and LN_FOLD == "0" and not LN_DIRECT:
             # 28x50 level: q-projection, attention over the <= 128 context keys and out-projection + residual in ONE
             # launch (csrc/xattn.hip); it owns whole rows, so it also emits the next sub-layer's LayerNorm
             xn = x2d if norm is None else norm.run(x2d)
             lno = (ln_next.weight, ln_next.bias, ln_next.eps) if LN_PRODUCER and isinstance(ln_next, LayerNorm) else None
-            out = O.xattn320(xn, self.to_q.w2d, self.to_out[0].w2d, self.to_out[0].bias, kv[:, :c], kv[:, c:], batch, lq,
+            out = O.xattn320(xn, self.to_q.wx, self.to_out[0].wx, self.to_out[0].bias, kv[:, :c], kv[:, c:], batch, lq,
                              lk, self.scale, res=res, ln_out=lno)
             if lno is not None:
                 out._ln_cache = (ln_next, out._ln_out)

@@ -54,12 +54,12 @@ class txt_con_XFormersAttn(_SFABase):
                 or self.__dict__["_pk_kv"].device != x.device:
             self.__dict__["_pk_kv"] = torch.cat([self.to_k.weight.detach(), self.to_v.weight.detach()], 0).contiguous()
         from . import layers
-        if layers.XATTN_FUSED and O.xattn320_ok(c, self.heads, lk) and x.shape[1] == c:
+        if layers.XATTN_FUSED and O.xattn320_ok(c, self.heads, lk, x.shape[0]) and x.shape[1] == c:
             # to_q -> attention over the text keys -> to_out + bias + residual in ONE launch (csrc/xattn.hip); K | V of
             # the text tokens as one contiguous [keys][40] block per head (the form the kernel streams fastest)
             hd = self.heads
             kvh = O.gemm(e2d, self.__dict__["_pk_kv"], head_major=(c // hd, 0, 1.0))        # (16, b * lk, 40)
-            return O.xattn320(x, self.to_q.w2d, self.to_out[0].w2d, self.to_out[0].bias, kvh[:hd], kvh[hd:], b, lq, lk,
+            return O.xattn320(x, self.to_q.wx, self.to_out[0].wx, self.to_out[0].bias, kvh[:hd], kvh[hd:], b, lq, lk,
                               self.scale, res=x if self.residual_connection else None)
         kv = O.gemm(e2d, self.__dict__["_pk_kv"])
         q = self.to_q.run(x)

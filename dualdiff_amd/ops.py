@@ -858,30 +858,40 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
 _ZERO_BIAS = {}
 
 
-def xattn320_ok(c, heads, lk):
-    """Shapes the fused cross-attention kernel covers (dd_xattn320): the 320-channel level, 8 heads, <= 128 keys."""
+# dd_xattn320 owns 80-row tiles, one workgroup per CU (135 KB of LDS), and every workgroup re-stages both 205 KB weight
+# matrices: it beats the three-launch form while its grid is ONE residency generation (12 instances x 1400 rows = 210
+# workgroups on 256 CUs: 40 vs 45 us for the SFA module) and loses beyond it (48 instances = 840 workgroups: 127 vs 114 us,
+# profiles/r03_sfa_roofline.txt).  Above this many workgroups the callers take the three launches.
+XATTN_MAX_WGS = int(_os.environ.get("DD_XATTN_MAX_WGS", "256"))
+
+
+def xattn320_ok(c, heads, lk, rows=None):
+    """Shapes the fused cross-attention kernel covers (dd_xattn320): the 320-channel level, 8 heads, <= 128 keys — and,
+    when the caller states its row count, a grid of at most XATTN_MAX_WGS 80-row workgroups."""
+    if rows is not None and (int(rows) + 79) // 80 > XATTN_MAX_WGS:
+        return False
     return int(c) == 320 and int(heads) == 8 and 0 < int(lk) <= 128
 
 
-_XPACK = {}
-
-
-def xattn_packed_weight(w):
-    """[320, 320] Linear weight -> the K-step-major, pre-swizzled copy dd_xattn320 streams by linear LDS-DMA
-    (dd_xattn_pack_weight).  Cached per weight tensor (storage pointer + version counter)."""
-    key = (w.data_ptr(), w._version, w.dtype, str(w.device))
-    hit = _XPACK.get(id(w))
-    if hit is not None and hit[0] == key:
-        return hit[1]
+def xattn_pack_weight(w):
+    """[320, 320] Linear weight -> the K-step-major, pre-swizzled 1-D copy dd_xattn320 streams by linear LDS-DMA
+    (dd_xattn_pack_weight).  NOT cached here: the owning module keeps the copy as a `_pk_*` entry beside its other packed
+    weights (layers.Linear.wx), so it lives exactly as long as the module, is dropped by `_drop_cache` on .to() /
+    load_state_dict, and can never be evicted under a captured HIP graph that holds its address (a
+    process-global, size-capped cache could free buffers a graph still replays from)."""
     if tuple(w.shape) != (320, 320) or not w.is_contiguous():
         raise ValueError("xattn320 weights must be contiguous (320, 320)")
+    _need_gpu(w)
     lib = _native.load()
     packed = torch.empty(320 * 320, dtype=w.dtype, device=w.device)
     _native.check(lib.dd_xattn_pack_weight(_ptr(w), _ptr(packed), _dt(w), _stream()), "xattn_pack_weight")
-    if len(_XPACK) > 256:
-        _XPACK.clear()
-    _XPACK[id(w)] = (key, packed, w)          # keeps `w` alive so that id(w) cannot be recycled under the entry
     return packed
+
+
+def _xpacked(w):
+    """Packed weights are 1-D (102400,); a raw (320, 320) weight is packed on the spot (uncached: a fresh buffer, which
+    inside a capture belongs to the graph's own pool)."""
+    return w if w.dim() == 1 and w.numel() == 320 * 320 else xattn_pack_weight(w)
 
 
 def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=None, ln_out=None, out=None):
@@ -889,7 +899,7 @@ def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=No
     residual, one launch (include/dualdiff_hip.h: dd_xattn320).  x: (instances * rows_per_inst, 320); k / v: either
     (instances * lk, >= 320) row-strided 2-D views (column slices of a wider projection) or HEAD-MAJOR 3-D tensors
     (8, instances * lk, 40) — slices of a `gemm(..., head_major=(40, 0, 1.0))` result, the form the kernel streams
-    fastest; wq / wo: the (320, 320) Linear weights (packed and cached here); ln_out = (gamma, beta, eps):
+    fastest; wq / wo: the packed copies of the (320, 320) Linear weights (xattn_pack_weight; layers.Linear.wx) or the raw weights; ln_out = (gamma, beta, eps):
     LayerNorm(out) comes back as `out._ln_out`."""
     lib = _native.load()
     _need_gpu(x, wq, wo, bo, k, v, res, out)
@@ -912,7 +922,7 @@ def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=No
     else:
         _forget_derived(out)
     out = _rows2d(out)
-    wqp, wop = xattn_packed_weight(wq), xattn_packed_weight(wo)
+    wqp, wop = _xpacked(wq), _xpacked(wo)
     d = XAttnDesc()
     d.x, d.ldx = x.data_ptr(), x.stride(0)
     if res is not None:

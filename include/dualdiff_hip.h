@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 1
+/* 2 (round 4): dd_gemm_desc gained splitk_inkernel / prefetch / prefetch_bytes and dd_attn_desc kv_batch_map2 in round 3
+ * without a bump; the GroupNorm workspace's first 256 B are barrier state.  A binding must check BOTH the version and the
+ * descriptor sizes (dd_desc_size) before the first launch: a stale pair would read past the caller's struct. */
+#define DD_ABI_VERSION 2
 
 enum { DD_F16 = 0, DD_BF16 = 1 };
 
@@ -41,6 +44,9 @@ enum {
 typedef void* dd_stream_t; /* hipStream_t */
 
 int dd_abi_version(void);
+/* sizeof() of descriptor `which` as THIS library was compiled: 0 dd_gemm_desc, 1 dd_attn_desc, 2 dd_xattn_desc,
+ * 3 dd_gemm8_desc; -1 for an unknown index.  The binding compares with its own struct sizes at load time. */
+int64_t dd_desc_size(int which);
 const char* dd_error_string(int code);
 /* Reports the compile-time gfx target string ("gfx950"). */
 const char* dd_target_arch(void);

@@ -222,7 +222,7 @@ def step_inputs(b=2, nbox=None, ltxt=None):
     g = torch.Generator().manual_seed(7)
     return {
         "sample": bf16_round(seeded_tensor((b, N_CAM, 4, H, W), 11)),
-        "timestep": torch.tensor([981.0, 41.0][:b]),
+        "timestep": torch.tensor([981, 41][:b]),          # int64 like the scheduler hands them over (pipeline_bev_controlnet.py:381); a float tensor would be cast to the storage dtype with the other inputs (bf16: 981 -> 980)
         "camera_param": bf16_round(seeded_tensor((b, N_CAM, 3, 7), 12)),
         "text": bf16_round(seeded_tensor((b, STEP_LTXT, 768), 13)),
         "boxes_bg": {"bboxes": bf16_round((torch.rand((b, N_CAM, STEP_NBOX, 8, 3), generator=g) - 0.5) * 20.0),

@@ -29,7 +29,11 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "%s declared in the header but not exported" % name
     assert sorted(_native.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert lib.dd_abi_version() == 1
+    assert lib.dd_abi_version() == _native.ABI_VERSION == 2
+    import ctypes
+    for which, st in enumerate((_native.GemmDesc, _native.AttnDesc, _native.XAttnDesc, _native.Gemm8Desc)):
+        assert lib.dd_desc_size(which) == ctypes.sizeof(st), st.__name__
+    assert lib.dd_desc_size(99) == -1
     assert lib.dd_target_arch() == b"gfx950"
     assert b"workspace" in lib.dd_error_string(-4)
 

@@ -69,7 +69,7 @@ m = txt_con_XFormersAttn().to(dev, dt)
 for p in m.parameters():
     p.data.normal_(0, 0.03)
 with torch.no_grad():
-    for inst in (48, 12):
+    for inst in (48, 24, 18, 12):
         rows = inst * LQ
         xx, ee = r(rows, C), r(inst * LK, 768)
         kv = r(inst * LK, 2 * C)
@@ -78,14 +78,15 @@ with torch.no_grad():
         fl = 4.0 * rows * C * C + 4.0 * inst * H * LQ * LK * D
         by = 2.0 * (3 * rows * C + 2 * C * C + inst * LK * 2 * C)          # x in, residual (the same tensor: L2), out
         row("to_q + SDPA + to_out + bias + residual (1 launch)",
-            lambda: O.xattn320(xx, m.to_q.w2d, m.to_out[0].w2d, m.to_out[0].bias, kvh[:H], kvh[H:], inst, LQ, LK, D ** -0.5, res=xx),
+            lambda: O.xattn320(xx, m.to_q.wx, m.to_out[0].wx, m.to_out[0].bias, kvh[:H], kvh[H:], inst, LQ, LK, D ** -0.5, res=xx),
             fl, by)
         row("  same, K / V as row-major column slices",
-            lambda: O.xattn320(xx, m.to_q.w2d, m.to_out[0].w2d, m.to_out[0].bias, kv[:, :C], kv[:, C:], inst, LQ, LK, D ** -0.5, res=xx),
+            lambda: O.xattn320(xx, m.to_q.wx, m.to_out[0].wx, m.to_out[0].bias, kv[:, :C], kv[:, C:], inst, LQ, LK, D ** -0.5, res=xx),
             fl, by)
-        for fused in (True, False):
-            _layers.XATTN_FUSED = fused
-            print("  module as called (to_k|to_v GEMM + %s): %.1f us" % ("fused kernel" if fused else "3 launches",
-                                                                          graph_time(lambda: m.run(xx, inst, LQ, ee, LK))))
-        _layers.XATTN_FUSED = True
+        cap = O.XATTN_MAX_WGS
+        for label, fused, wgs in (("fused kernel forced", True, 1 << 30), ("3 launches forced", False, cap),
+                                  ("as DISPATCHED (fused iff <= %d workgroups)" % cap, True, cap)):
+            _layers.XATTN_FUSED, O.XATTN_MAX_WGS = fused, wgs
+            print("  module as called (to_k|to_v GEMM + %s): %.1f us" % (label, graph_time(lambda: m.run(xx, inst, LQ, ee, LK))))
+        _layers.XATTN_FUSED, O.XATTN_MAX_WGS = True, cap
         print()
