@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the whole GPU suite (parity CSV -> gpurun_out/<tag>_parity.csv) followed by the profile refresh.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/r03_parity.csv
+rm -f gpurun_out/r04_parity.csv
 timeout 4200 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/${TAG}_tests.log
 tail -4 gpurun_out/${TAG}_tests.log
