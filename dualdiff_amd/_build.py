@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libdualdiff_hip.so"
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "xattn.hip", "gemm8.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "xattn.hip", "gemm8.hip", "tokens.hip"]
 # per-source extra flags: the attention softmax lives on the MFMA results, so ask LLVM for the
 # VGPR-destination form of MFMA (gfx950 has a unified register file) instead of AGPR accumulators
 # that cost a v_accvgpr_read/write per touched element.

@@ -57,6 +57,19 @@ class AttnDesc(Structure):
     ]
 
 
+class BoxTokensDesc(Structure):
+    _fields_ = [
+        ("points", c_void_p), ("classes", c_void_p), ("masks", c_void_p),
+        ("class_tokens", c_void_p), ("null_pos", c_void_p), ("null_class", c_void_p),
+        ("pos", c_void_p), ("cat", c_void_p), ("cls_out", c_void_p),
+        ("rows", c_int32), ("points_per_box", c_int32), ("num_freqs", c_int32), ("include_input", c_int32),
+        ("class_token_dim", c_int32), ("cls_offset", c_int32),
+        ("ld_cat", c_int64),
+        ("normalize", c_int32), ("points_dtype", c_int32), ("dtype", c_int32), ("reserved", c_int32),
+        ("freqs", c_float * 16), ("xyz_min", c_float * 3), ("xyz_range", c_float * 3),
+    ]
+
+
 class XAttnDesc(Structure):
     _fields_ = [
         ("x", c_void_p), ("ldx", c_int64), ("res", c_void_p), ("ldres", c_int64),
@@ -109,6 +122,13 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
                                       c_int32, c_void_p]),
     "dd_xattn320": (c_int32, [POINTER(XAttnDesc), c_void_p]),
+    "dd_nchw_to_nhwc_views": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                        c_void_p]),
+    "dd_fourier_embed_strided": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, POINTER(c_float), c_int32, c_int32,
+                                           c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "dd_box_tokens": (c_int32, [POINTER(BoxTokensDesc), c_void_p]),
+    "dd_ctx_assemble": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "dd_gemm8": (c_int32, [POINTER(Gemm8Desc), c_void_p]),
     "dd_rowquant_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_float,
                                   c_int32, c_void_p]),
@@ -165,7 +185,7 @@ def load(build_if_missing=True):
     if lib.dd_abi_version() != ABI_VERSION:
         raise RuntimeError("dualdiff_amd: %s has ABI version %d, this binding needs %d (rebuild: __graft_entry__.build())"
                            % (path, lib.dd_abi_version(), ABI_VERSION))
-    for which, st in enumerate((GemmDesc, AttnDesc, XAttnDesc, Gemm8Desc)):
+    for which, st in enumerate((GemmDesc, AttnDesc, XAttnDesc, Gemm8Desc, BoxTokensDesc)):
         if lib.dd_desc_size(which) != ctypes.sizeof(st):      # a stale library would read past (or ignore) our fields
             raise RuntimeError("dualdiff_amd: %s was built with a different %s (%d bytes, binding has %d)"
                                % (path, st.__name__, lib.dd_desc_size(which), ctypes.sizeof(st)))

@@ -652,6 +652,7 @@ extern "C" int64_t dd_desc_size(int which) {
     case 1: return (int64_t)sizeof(dd_attn_desc);
     case 2: return (int64_t)sizeof(dd_xattn_desc);
     case 3: return (int64_t)sizeof(dd_gemm8_desc);
+    case 4: return (int64_t)sizeof(dd_box_tokens_desc);
   }
   return -1;
 }

@@ -13,6 +13,7 @@ from .. import ops as O
 from .embedder import get_embedder
 from .layers import Linear
 
+FUSED_BOX_TOKENS = __import__("os").environ.get("DD_FUSED_TOKENS", "1") != "0"      # one launch for both MLP operands (ops.box_tokens); False = the tensor-op chain
 XYZ_MIN = [-200, -300, -20]
 XYZ_RANGE = [350, 650, 80]
 
@@ -95,6 +96,25 @@ class ContinuousBBoxWithTextEmbedding(nn.Module):
         b, n = classes.shape
         dt = self.null_pos_feature.dtype
         pts = bboxes.reshape(b * n, *bboxes.shape[2:])
+        fe = self.fourier_embedder
+        if FUSED_BOX_TOKENS and pts.is_cuda and pts.dim() == 3 and pts.shape[-1] == 3 and len(fe.freq_bands) <= 16 and dt in (torch.float16, torch.bfloat16) \
+                and pts.dtype in (torch.float16, torch.bfloat16, torch.float32) and self.class_tokens.dtype == dt:
+            # GPU path: ONE launch writes both operands of the MLP — the (masked) Fourier features and the (masked) class
+            # token in the right half of the concat buffer; bbox_proj's SiLU epilogue fills the left half in place.
+            # Bit-identical to the tensor-op chain below (a 0 / 1 mask blend of finite values is a select).
+            rows, pd = b * n, self.bbox_proj.out_features
+            ctd = self.class_tokens.shape[1]
+            pos = torch.empty((rows, self.bbox_proj.in_features), dtype=dt, device=pts.device)
+            cat = torch.empty((rows, pd + ctd), dtype=dt, device=pts.device)
+            cls = torch.empty((rows, ctd), dtype=dt, device=pts.device) if return_cls_emb else None
+            O.box_tokens(pts, classes.reshape(-1), None if masks is None else masks.reshape(-1), self.class_tokens,
+                         self.null_pos_feature, self.null_class_feature, fe.freq_bands, fe.include_input, pos, cat, pd,
+                         cls_out=cls, normalize=(XYZ_MIN, XYZ_RANGE) if self.minmax_normalize else None)
+            self.bbox_proj.run(pos, epilogue=O.DD_EPI_SILU, out=cat[:, :pd])
+            emb = self.second_linear.run(cat).reshape(b, n, -1)
+            if return_cls_emb:
+                return emb, cls.reshape(b, n, -1)
+            return emb
         if masks is None:
             masks = torch.ones(len(pts), device=pts.device)
         masks = masks.reshape(-1).unsqueeze(-1).to(dt)

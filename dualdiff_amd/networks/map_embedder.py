@@ -34,11 +34,8 @@ class ControlNetConditioningEmbedding(nn.Module):
         nv = int(n_views)
         w = pw // nv
         dt = self.conv_in.weight.dtype
-        # view split (map_embedder.py:116-125) + NHWC + channel pad to 8 in one boundary copy
-        x = conditioning.to(dt).reshape(b, c, h, nv, w).permute(0, 3, 2, 4, 1)      # b, view, h, w, c
-        xp = x.new_zeros((b, nv, h, w, self.conv_in.cin_pad))
-        xp[..., :c] = x
-        x = xp.reshape(b * nv * h * w, self.conv_in.cin_pad)
+        # view split (map_embedder.py:116-125) + NHWC + channel pad to 8: one layout launch
+        x = O.nchw_to_nhwc(conditioning.to(dt), self.conv_in.cin_pad, views=nv)
         m = b * nv
         x = self.conv_in.run(x, m, h, w, epilogue=O.DD_EPI_SILU)
         for blk in self.blocks:

@@ -282,7 +282,18 @@ class BEVControlNetModel(ModelBase):
         self.use_aug_text = use_aug_text
         dt = self.dtype
         b, n_cam = camera_param.shape[:2]
-        ctx = self.add_cam_states(encoder_hidden_states, self._embed_camera(camera_param))    # b, n, L+1, 768
+        m = b * n_cam
+        fe = self.cam_embedder
+        fused = FUSED_TOKENS and camera_param.is_cuda and dt in (torch.float16, torch.bfloat16) and len(fe.freq_bands) <= 16 \
+            and camera_param.dtype in (torch.float16, torch.bfloat16, torch.float32)
+        if fused:
+            # camera tokens: Fourier features of the 7 column vectors, transposed read and K padding inside ONE launch,
+            # then cam2token (:308-325, :349-353)
+            kp = self.cam2token.w2d.shape[1]
+            cam = O.gemm(O.camera_features(camera_param, fe.freq_bands, fe.include_input, dt, kp), self.cam2token.w2d,
+                         self.cam2token.bias)
+        else:
+            ctx = self.add_cam_states(encoder_hidden_states, self._embed_camera(camera_param))    # b, n, L+1, 768
         box = cls = None
         if bboxes_3d_data is not None:
             nb = bboxes_3d_data["bboxes"].shape[1]
@@ -295,14 +306,24 @@ class BEVControlNetModel(ModelBase):
             box = box.reshape(b, nb, *box.shape[1:])
             if nb != n_cam:
                 assert nb == 1, "either N_cam or 1."
-                box = box.expand(-1, n_cam, -1, -1)
+                if not fused:
+                    box = box.expand(-1, n_cam, -1, -1)
                 cls = None if cls is None else cls.expand(-1, n_cam, -1, -1)
-        m = b * n_cam
-        ctx = ctx.reshape(m, ctx.shape[2], ctx.shape[3])
-        full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1065-1068
-        full = full.contiguous()
+        if fused:
+            # [cam | text | box] per view-instance and the text tokens alone (:337-361, :1007, :977): one gather-copy;
+            # view-shared boxes / per-scene text are index arithmetic of the kernel, not expand + cat + contiguous
+            e = encoder_hidden_states.to(dt)
+            bx = None if box is None else box.reshape(b * box.shape[1], *box.shape[2:]).to(dt)
+            full, txt = O.ctx_assemble(cam, e, bx, n_cam, text_per_view=bool(self.use_aug_text))
+            if box is not None and nb != n_cam:
+                box = box.expand(-1, n_cam, -1, -1)
+        else:
+            ctx = ctx.reshape(m, ctx.shape[2], ctx.shape[3])
+            full = ctx if box is None else torch.cat([ctx, box.reshape(m, *box.shape[2:]).to(dt)], dim=1)   # :1065-1068
+            full = full.contiguous()
+            txt = ctx[:, 1:].contiguous()
         out = {"ctx": full, "ctx2d": full.reshape(-1, full.shape[-1]), "lc": full.shape[1], "m": m,
-               "txt": ctx[:, 1:].contiguous()}                      # text tokens without the camera token (:977)
+               "txt": txt}                                          # text tokens without the camera token (:977)
         # the ControlNet's own cross-attentions additionally see the class tokens when the adapter is on
         # (:1006,:1021); the UNet never does (:1065-1068)
         if cls is not None:
@@ -427,6 +448,11 @@ class BEVControlNetModel(ModelBase):
             return down, mid, ctx
         return BEVControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid,
                                    encoder_hidden_states_with_cam=ctx)
+
+
+# token preparation as four launches (csrc/tokens.hip) instead of ~20 tensor ops per branch; False = the tensor-op chain
+# (tests compare the two bit for bit)
+FUSED_TOKENS = __import__("os").environ.get("DD_FUSED_TOKENS", "1") != "0"
 
 
 def _own_path(dotted):

@@ -991,15 +991,20 @@ def silu(x, out=None):
     return out
 
 
-def nchw_to_nhwc(x, c_pad=None):
-    """(m, c, h, w) contiguous -> (m*h*w, c_pad) with zero-padded channels."""
+def nchw_to_nhwc(x, c_pad=None, views=1):
+    """(m, c, h, views * w) contiguous -> (m * views * h * w, c_pad) NHWC rows with zero-padded channels (c_pad rounded up to
+    a multiple of 8); views > 1 also splits a panorama into its views (map_embedder.py:116-125).  One LDS-tiled launch,
+    both sides coalesced (csrc/tokens.hip)."""
     lib = _native.load()
     _need_gpu(x)
-    m, c, h, w = x.shape
-    c_pad = c if c_pad is None else c_pad
+    m, c, h, wt = x.shape
+    if wt % views:
+        raise ValueError("nchw_to_nhwc: width %d is not %d views" % (wt, views))
+    c_pad = (c if c_pad is None else c_pad)
+    c_pad = (c_pad + 7) // 8 * 8
     x = x.contiguous()
-    out = torch.empty((m * h * w, c_pad), dtype=x.dtype, device=x.device)
-    rc = lib.dd_nchw_to_nhwc(_ptr(x), _ptr(out), m, c, h * w, c_pad, _dt(x), _stream())
+    out = torch.empty((m * views * h * (wt // views), c_pad), dtype=x.dtype, device=x.device)
+    rc = lib.dd_nchw_to_nhwc_views(_ptr(x), _ptr(out), m, c, h, wt // views, views, c_pad, _dt(x), _stream())
     _native.check(rc, "nchw_to_nhwc")
     return out
 
@@ -1109,11 +1114,14 @@ def ors_project(occ, origin, direction, samples, step=0.2, *, want_labels=True, 
     return labels, cond
 
 
+_FDT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+
+
 def fourier_embed(x, freqs, include_input=True):
     """[x, sin(f0 x), cos(f0 x), ...] on the last dim (networks/embedder.py), one kernel."""
     lib = _native.load()
     _need_gpu(x)
-    code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(x.dtype)
+    code = _FDT.get(x.dtype)
     if code is None:
         raise TypeError("fourier_embed takes fp16 / bf16 / fp32 tensors, got %s" % x.dtype)
     x = x.contiguous()
@@ -1125,6 +1133,90 @@ def fourier_embed(x, freqs, include_input=True):
     _native.check(lib.dd_fourier_embed(_ptr(x), _ptr(out), rows, dims, arr, nf, int(include_input), code, code,
                                        _stream()), "fourier_embed")
     return out
+
+
+def camera_features(camera_param, freqs, include_input, dtype, k_pad):
+    """(b, n, 3, j) camera parameters -> (b * n, k_pad) Fourier features of the j column vectors, back to back, in
+    `dtype`, zero-padded from j * 3 * (include_input + 2 F) to k_pad columns — `cam_embedder(camera_param.permute(0, 1,
+    3, 2)).reshape(b, n, -1)` of unet_addon_rawbox.py:308-325 plus the K padding of cam2token, in ONE launch (the
+    transposed read and the padding are strides of the kernel)."""
+    lib = _native.load()
+    _need_gpu(camera_param)
+    code = _FDT.get(camera_param.dtype)
+    if code is None or camera_param.dim() != 4:
+        raise TypeError("camera_features takes a (b, n, 3, j) fp16 / bf16 / fp32 tensor")
+    x = camera_param.contiguous()
+    b, n, dims, j = x.shape
+    nf = len(freqs)
+    width = dims * ((1 if include_input else 0) + 2 * nf)
+    if not j * width <= k_pad <= j * width + dims:
+        raise ValueError("camera_features: k_pad %d does not fit %d features" % (k_pad, j * width))
+    out = torch.empty((b * n, k_pad), dtype=dtype, device=x.device)
+    arr = (ctypes.c_float * nf)(*[float(f) for f in freqs])
+    rc = lib.dd_fourier_embed_strided(_ptr(x), _ptr(out), b * n * j, dims, arr, nf, int(include_input), code, _FDT[dtype],
+                                      j, dims * j, 1, j, k_pad, _stream())
+    _native.check(rc, "camera_features")
+    return out
+
+
+def box_tokens(points, classes, masks, class_tokens, null_pos, null_class, freqs, include_input, pos, cat, cls_offset,
+               cls_out=None, normalize=None):
+    """Both operands of the box MLP in one launch (include/dualdiff_hip.h: dd_box_tokens; bbox_embedder.py:164-203).
+    points (rows, P, 3) fp16 / bf16 / fp32; classes (rows,) int64; masks (rows,) bool or None; pos (rows, P * 3 * (inc + 2
+    F)) and cat (rows, >= cls_offset + D) are written in place (dtype of class_tokens); normalize = (xyz_min, xyz_range)."""
+    lib = _native.load()
+    _need_gpu(points, classes, masks, class_tokens, null_pos, null_class, pos, cat, cls_out)
+    rows, npts = points.shape[0], points.shape[1]
+    d = _native.BoxTokensDesc()
+    points, classes = points.contiguous(), classes.contiguous()
+    if classes.dtype != torch.int64:
+        classes = classes.long()
+    if masks is not None:
+        masks = masks.contiguous()
+        masks = masks.view(torch.uint8) if masks.dtype == torch.bool else (masks != 0).view(torch.uint8)
+    code = _FDT.get(points.dtype)
+    if code is None or points.shape[2] != 3 or not pos.is_contiguous() or cat.stride(1) != 1:
+        raise TypeError("box_tokens: points (rows, P, 3) in fp16 / bf16 / fp32, pos contiguous, cat row-major")
+    nf = len(freqs)
+    if tuple(pos.shape) != (rows, npts * 3 * ((1 if include_input else 0) + 2 * nf)) or pos.dtype != class_tokens.dtype \
+            or cat.dtype != class_tokens.dtype or cat.shape[0] != rows:
+        raise ValueError("box_tokens: operand shapes / dtypes do not match")
+    d.points, d.classes, d.masks = points.data_ptr(), classes.data_ptr(), (masks.data_ptr() if masks is not None else None)
+    d.class_tokens, d.null_pos, d.null_class = class_tokens.data_ptr(), null_pos.data_ptr(), null_class.data_ptr()
+    d.pos, d.cat, d.cls_out = pos.data_ptr(), cat.data_ptr(), (cls_out.data_ptr() if cls_out is not None else None)
+    d.rows, d.points_per_box, d.num_freqs, d.include_input = rows, npts, nf, int(include_input)
+    d.class_token_dim, d.cls_offset, d.ld_cat = class_tokens.shape[1], int(cls_offset), cat.stride(0)
+    d.points_dtype, d.dtype = code, _dt(class_tokens)
+    for i, f in enumerate(freqs):
+        d.freqs[i] = float(f)
+    if normalize is not None:
+        d.normalize = 1
+        for i in range(3):
+            d.xyz_min[i], d.xyz_range[i] = float(normalize[0][i]), float(normalize[1][i])
+    _native.check(lib.dd_box_tokens(ctypes.byref(d), _stream()), "box_tokens")
+
+
+def ctx_assemble(cam, text, box, n_cam, text_per_view=False, want_txt=True):
+    """[cam_i | text | box tokens] per view-instance, and the text tokens alone (unet_addon_rawbox.py:337-361, :1007,
+    :977) in one gather-copy.  cam (m, D); text (scenes, L, D) or (m, L, D) with text_per_view; box (scenes * v, N, D)
+    with v in {n_cam, 1}, or None.  Returns (full (m, 1 + L + N, D), txt (m, L, D) or None)."""
+    lib = _native.load()
+    _need_gpu(cam, text, box)
+    m, dim = cam.shape
+    lt = text.shape[1]
+    scenes = m // n_cam
+    nbox = 0 if box is None else box.shape[1]
+    box_views = n_cam if box is None else box.shape[0] // scenes
+    if text.shape[0] != (m if text_per_view else scenes) or (box is not None and box.shape[0] not in (scenes, m)):
+        raise ValueError("ctx_assemble: text / box batch does not match %d scenes x %d views" % (scenes, n_cam))
+    cam, text = cam.contiguous(), text.contiguous()
+    box = None if box is None else box.contiguous()
+    full = torch.empty((m, 1 + lt + nbox, dim), dtype=cam.dtype, device=cam.device)
+    txt = torch.empty((m, lt, dim), dtype=cam.dtype, device=cam.device) if want_txt else None
+    rc = lib.dd_ctx_assemble(_ptr(cam), _ptr(text), _ptr(box), _ptr(full), _ptr(txt), m, n_cam, lt, nbox, dim,
+                             int(text_per_view), box_views, _dt(cam), _stream())
+    _native.check(rc, "ctx_assemble")
+    return full, txt
 
 
 def quantize_fp8(w):

@@ -45,7 +45,7 @@ typedef void* dd_stream_t; /* hipStream_t */
 
 int dd_abi_version(void);
 /* sizeof() of descriptor `which` as THIS library was compiled: 0 dd_gemm_desc, 1 dd_attn_desc, 2 dd_xattn_desc,
- * 3 dd_gemm8_desc; -1 for an unknown index.  The binding compares with its own struct sizes at load time. */
+ * 3 dd_gemm8_desc, 4 dd_box_tokens_desc; -1 for an unknown index.  The binding compares with its own struct sizes at load time. */
 int64_t dd_desc_size(int which);
 const char* dd_error_string(int code);
 /* Reports the compile-time gfx target string ("gfx950"). */
@@ -349,6 +349,49 @@ int dd_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim,
 int dd_fourier_embed(const void* x, void* out, int64_t rows, int32_t dims, const float* freqs,
                      int32_t num_freqs, int32_t include_input, int32_t in_dtype, int32_t out_dtype,
                      dd_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Token / condition preparation of a ControlNet branch (csrc/tokens.hip, round 4): what the reference does with ~40
+ * tiny torch ops per step (unet_addon_rawbox.py:308-361,832-896,1007; bbox_embedder.py:164-203;
+ * map_embedder.py:116-125) as four launches.
+ * ------------------------------------------------------------------------- */
+/* NCHW (m, c, h, views * w) -> NHWC rows of m * views instances (h, w, c_pad), channels zero-padded; views = 1 is the
+ * plain layout change (LDS-tiled: both sides coalesced), views = 6 the panorama split of map_embedder.py:116-125.
+ * c_pad % 8 == 0, y 16-byte aligned. */
+int dd_nchw_to_nhwc_views(const void* x, void* y, int32_t m, int32_t c, int32_t h, int32_t w, int32_t views,
+                          int32_t c_pad, int32_t dtype, dd_stream_t stream);
+/* dd_fourier_embed with a strided source and a padded destination: row r = outer * inner + j reads its `dims` inputs at
+ * x[outer * stride_outer + j * stride_inner + d * stride_dim] and writes its features at
+ * out[outer * out_ld + j * width ...], width = dims * (include_input + 2 * num_freqs); the out_ld - inner * width
+ * (<= dims) trailing columns of every outer row are zeroed (K padding of the Linear that follows).  Camera parameters
+ * (b, n, 3, 7) -> (b n, 189 padded to 192): dims 3, inner 7, strides (21, 1, 7) (unet_addon_rawbox.py:308-325). */
+int dd_fourier_embed_strided(const void* x, void* out, int64_t rows, int32_t dims, const float* freqs,
+                             int32_t num_freqs, int32_t include_input, int32_t in_dtype, int32_t out_dtype,
+                             int32_t inner, int64_t stride_outer, int64_t stride_inner, int64_t stride_dim,
+                             int64_t out_ld, dd_stream_t stream);
+/* Both operands of the box MLP (bbox_embedder.py:164-203).  For every box r: pos[r] = masks[r] ? Fourier features of its
+ * points : null_pos  (T [rows][points_per_box * 3 * (include_input + 2 num_freqs)], the input of bbox_proj), and
+ * cat[r][cls_offset ...] = masks[r] ? class_tokens[classes[r]] : null_class  (the right half of the concat
+ * second_linear reads; bbox_proj writes the left half); cls_out (optional) gets the same class rows (box adapter).
+ * points: [rows][points_per_box][3] in `points_dtype` (DD_F16 / DD_BF16 / DD_F32; values pass through that dtype as in
+ * the reference); classes int64; masks uint8 (NULL = keep all); normalize: (p - xyz_min) / xyz_range first. */
+typedef struct dd_box_tokens_desc {
+  const void* points; const int64_t* classes; const uint8_t* masks;
+  const void* class_tokens; const void* null_pos; const void* null_class;
+  void* pos; void* cat; void* cls_out;
+  int32_t rows, points_per_box, num_freqs, include_input, class_token_dim, cls_offset;
+  int64_t ld_cat;
+  int32_t normalize, points_dtype, dtype, reserved;
+  float freqs[16]; float xyz_min[3]; float xyz_range[3];
+} dd_box_tokens_desc;
+int dd_box_tokens(const dd_box_tokens_desc* d, dd_stream_t stream);
+/* Context assembly: full[i] = [cam_i | text | box tokens] and (optional) txt[i] = text for instance i = (scene, view)
+ * (unet_addon_rawbox.py:337-361, :1007, :977).  cam [m][dim]; text [scenes][lt][dim] (text_per_view: [m][lt][dim]);
+ * box [scenes * box_views][nbox][dim], box_views in {n_cam, 1} (NULL when nbox == 0); full [m][1 + lt + nbox][dim];
+ * txt [m][lt][dim] or NULL.  dim % 8 == 0, all 16-byte aligned. */
+int dd_ctx_assemble(const void* cam, const void* text, const void* box, void* full, void* txt, int32_t m,
+                    int32_t n_cam, int32_t lt, int32_t nbox, int32_t dim, int32_t text_per_view, int32_t box_views,
+                    int32_t dtype, dd_stream_t stream);
 
 /* ORS projection (networks/occ3d_proj.py:49-113 + dataset/utils.py:412-420): every
  * latent pixel's ray is sampled at `samples` equidistant points (step metres apart) in a

@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_native.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
     assert lib.dd_abi_version() == _native.ABI_VERSION == 2
     import ctypes
-    for which, st in enumerate((_native.GemmDesc, _native.AttnDesc, _native.XAttnDesc, _native.Gemm8Desc)):
+    for which, st in enumerate((_native.GemmDesc, _native.AttnDesc, _native.XAttnDesc, _native.Gemm8Desc,
+                              _native.BoxTokensDesc)):
         assert lib.dd_desc_size(which) == ctypes.sizeof(st), st.__name__
     assert lib.dd_desc_size(99) == -1
     assert lib.dd_target_arch() == b"gfx950"
