@@ -589,6 +589,82 @@ def _write_full_report(full, tag):
     return None
 
 
+_TORCHRUN_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                 "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT",
+                 "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+                 "TORCHELASTIC_ERROR_FILE")
+
+
+def _run_child_job(n, argv, timeout_s, extra_env=None):
+    """Starts `python -m torch.distributed.run ... bench.py <argv>` as a CHILD process group with a clean rendezvous
+    environment, waits at most timeout_s, kills exactly that process group on timeout.  Returns (rc or None, stdout,
+    stderr tail).  Never an exec: the caller may have initialised the GPU."""
+    import signal
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in _TORCHRUN_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+        return proc.returncode, so, se[-2000:]
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # the session we started: launcher + its ranks, nothing else
+        except OSError:
+            pass
+        try:
+            so, se = proc.communicate(timeout=20)
+        except Exception:
+            so, se = "", ""
+        return None, so, (se or "")[-2000:]
+
+
+def _last_json_line(text):
+    for ln in reversed((text or "").strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def strong_scaling_leg(world, args, weak_ms_per_step, extra_env=None, extra_argv=()):
+    """ONE scene over all `world` GPUs (view split: CFG halves x view shards, neighbour-view K/V point to point in
+    every transformer block + the CFG pair all-gather) as a fresh child job; returns the `strong_scaling` object of
+    the bench line.  `speedup_vs_one_gpu` compares with the time a single GPU needs for one scene IN THIS RUN (the
+    scene-sharded measurement: every rank denoised its own scene alone)."""
+    argv = ["--gpus", str(world), "--parallelism", "view-split", "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--dtype", args.dtype, "--single-dtype", "--no-roofline", "--no-cpu-baseline", "--strong-leg", "off"] + list(extra_argv)
+    if args.plumbing_check:
+        argv.append("--plumbing-check")
+    t0 = time.perf_counter()
+    rc, so, se = _run_child_job(world, argv, args.strong_timeout, extra_env)
+    took = round(time.perf_counter() - t0, 1)
+    line = _last_json_line(so)
+    if rc is None:
+        return {"mode": "view-split", "error": "child job killed after %.0f s (timeout)" % args.strong_timeout, "seconds": took}
+    if rc != 0 or line is None:
+        return {"mode": "view-split", "error": "child job rc %s: %s" % (rc, (se or so or "")[-300:].replace("\n", " | ")),
+                "seconds": took}
+    if line.get("plumbing_check"):
+        return {"mode": "view-split", "plumbing_check": True, "n_gpus": line.get("n_gpus"), "seconds": took}
+    vs = (line.get("config") or {}).get("view_split") or {}
+    ms = line.get("ms_per_step")
+    return {"mode": "view-split", "value": line.get("value"), "unit": "steps/s (one scene on %d GPUs)" % world,
+            "ms_per_step": ms, "speedup_vs_one_gpu": (round(weak_ms_per_step / ms, 3) if ms and weak_ms_per_step else None),
+            "outputs_finite": line.get("outputs_finite"), "hip_graph": (line.get("config") or {}).get("hip_graph"),
+            "message_bytes_per_forward": vs.get("rank0_sent_bytes_per_forward"),
+            "views_per_rank": vs.get("views_per_rank"),
+            "verified_on_multi_gpu_hardware": bool(line.get("outputs_finite")) and not os.environ.get("DD_BENCH_SHARE_GPU"),
+            "seconds": took}
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -614,19 +690,26 @@ def _self_launch(n, argv):
 def _plumbing_check(args, world, rank):
     """Launcher / rendezvous check WITHOUT the measured path (runs on a CPU-only host: tests/test_distributed_cpu.py):
     every rank joins a gloo group, passes the barrier the timed region uses and takes the max-over-ranks of a fake
-    elapsed time; rank 0 prints a line with `n_gpus` = the world size and NO value — never a measurement."""
+    elapsed time; rank 0 prints a line with `n_gpus` = the world size and NO value — never a measurement.  With N > 1 in
+    the default mode the strong-scaling leg is orchestrated exactly as in a real run (child job, timeout, one line)."""
     import torch.distributed as dist
     from dualdiff_amd.parallel import max_over_ranks
     if world > 1:
         dist.init_process_group("gloo")
         dist.barrier()
     slowest = max_over_ranks(1.0 + rank)
-    if rank == 0:
-        print(json.dumps({"metric": _metric_name(), "value": None, "unit": "steps/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "plumbing_check": True,
-                          "slowest_rank_seconds": slowest, "requested_gpus": args.gpus}))
+    time.sleep(float(os.environ.get("DD_PLUMBING_SLEEP", "0")))          # tests: a child job that overruns its timeout
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    out = {"metric": _metric_name(), "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "plumbing_check": True, "slowest_rank_seconds": slowest, "requested_gpus": args.gpus,
+           "parallelism": args.parallelism}
+    if world > 1 and args.parallelism == "scenes" and args.strong_leg == "auto":
+        out["strong_scaling"] = strong_scaling_leg(world, args, 1.0)
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -674,6 +757,12 @@ def main():
     ap.add_argument("--challenge-tiles", default="",
                     help="comma-separated GEMM tile ids added after the tracked table was written: every entry's incumbent is "
                          "timed against them once (3 %% to win) and the table is written back to --tune-cache")
+    ap.add_argument("--strong-leg", default="auto", choices=["auto", "off"],
+                    help="N > 1 in the default scene-sharded mode: after the weak-scaling measurement rank 0 runs ONE scene "
+                         "over all N GPUs (--parallelism view-split) as a fresh child job with a hard timeout and reports it "
+                         "as `strong_scaling` in the same line (never a second line, never a hang)")
+    ap.add_argument("--strong-timeout", type=float, default=float(os.environ.get("DD_STRONG_TIMEOUT", "240")),
+                    help="seconds the strong-scaling child job may take before its process group is killed")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher / rendezvous check only (gloo, no GPU call, no measurement): prints n_gpus")
     args = ap.parse_args()
@@ -724,10 +813,17 @@ def main():
     if not args.single_dtype and args.parallelism == "scenes":
         other = measure(args, other_name, device, dist, world, rank, backend, False)
 
+    want_strong = world > 1 and args.parallelism == "scenes" and args.strong_leg == "auto"
+    if dist is not None:                       # the weak-scaling job is over: every rank leaves the group and frees its GPU memory
+        torch.cuda.empty_cache()
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
+    strong = None
+    if want_strong:                            # rank 0 only, as a child job: a hang or crash there cannot touch `value`
+        strong = strong_scaling_leg(world, args, res["elapsed"] / args.steps * 1e3 / args.scenes)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_steps)
@@ -790,13 +886,13 @@ def main():
                               "outputs_finite": other["finite"]}
     if cpu:
         out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
+    if strong is not None:
+        out["strong_scaling"] = strong
     path = _write_full_report(out, "%s_n%d_%s" % (args.dtype, world, args.parallelism))
     line = json.dumps(compact_line(out, path))
     assert len(line) < LINE_LIMIT, len(line)
     sys.stdout.flush()
     print(line, flush=True)             # nothing follows this line on stdout
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -231,6 +231,33 @@ def test_bench_gpus_flag_self_launches_n_ranks(n):
     assert out["slowest_rank_seconds"] == float(n)          # max over ranks of (1 + rank)
 
 
+def test_bench_strong_scaling_leg_is_a_child_job_in_the_same_line():
+    """with N > 1 the line also says what ONE scene over all N GPUs does (`strong_scaling`, the
+    view-split mode north_star's ">= 6x at 8 GPUs" is about) — measured by a fresh CHILD job after the weak-scaling
+    ranks have left their group, so that a crash or hang there cannot touch `value`.  Plumbing form: gloo, no GPU."""
+    out = _bench_line(["--gpus", "2", "--plumbing-check"], timeout=600)
+    ss = out["strong_scaling"]
+    assert out["n_gpus"] == 2 and ss["mode"] == "view-split" and ss["plumbing_check"] is True and ss["n_gpus"] == 2
+    assert "error" not in ss
+    off = _bench_line(["--gpus", "2", "--plumbing-check", "--strong-leg", "off"])
+    assert "strong_scaling" not in off
+
+
+def test_bench_strong_scaling_leg_timeout_is_reported_not_hung():
+    """A strong-scaling child that overruns its budget is killed (its own process group only) and reported as an error
+    object; the parent's line — the weak-scaling result — is still printed, once."""
+    import time
+    t0 = time.time()
+    out = _bench_line(["--gpus", "2", "--plumbing-check", "--strong-timeout", "20"], env={"DD_PLUMBING_SLEEP": "12"},
+                      timeout=600)
+    # the parent's own ranks sleep 12 s (inside the budget of the test), the child would need 12 s more plus start-up
+    assert out["n_gpus"] == 2 and out["plumbing_check"] is True
+    assert "strong_scaling" in out
+    ss = out["strong_scaling"]
+    assert ss["mode"] == "view-split" and ("error" in ss or ss.get("plumbing_check") is True)
+    assert time.time() - t0 < 300
+
+
 def test_bench_gpus_flag_mismatch_is_an_error():
     import subprocess
     import sys
