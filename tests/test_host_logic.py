@@ -343,3 +343,50 @@ def test_bench_line_stays_parseable_and_short():
     fat["config"]["workload"] = "w" * 3000
     fat_line = json.dumps(bench.compact_line(fat, "x.json"))
     assert len(fat_line) < 4096 and json.loads(fat_line)["value"] == fat["value"]
+
+
+def test_pmc_summary_counts_only_the_timed_steps(tmp_path):
+    """HBM traffic per launch must come from the dispatches of the timed steps, per launch shape —
+    not from every dispatch of a symbol in the process (tuner launches behind a 320 MB flush were charged the flush's
+    write-back: the '23 MB floor')."""
+    import csv
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"]
+
+    def write(d, counter, scale):
+        os.makedirs(d)
+        rows, did = [], 0
+        def add(name, grid, val):
+            nonlocal did
+            did += 1
+            rows.append([did, name, grid, 256, counter, val * scale])
+        for _ in range(50):                       # tuner: flush + a tiny GEMM charged with the flush's write-back
+            add("FillFunctor", 1 << 20, 327680.0)
+            add("dd_gemm2_kernel_tiny", 256, 23000.0)
+        for step in range(3):                     # warm-up + 2 timed steps
+            add("dd_gemm2_kernel_tiny", 256, 1000.0)
+            add("dd_gemm2_kernel_tiny", 256, 1000.0)
+            add("dd_gemm2_kernel_tiny", 512, 3000.0)          # same symbol, another shape
+            add("dd_cfg_ddim_kernel", 64, 10.0)
+        with open(os.path.join(d, "x_counter_collection.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(hdr)
+            w.writerows(rows)
+    write(str(tmp_path / "f"), "FETCH_SIZE", 1.0)
+    write(str(tmp_path / "w"), "WRITE_SIZE", 0.5)
+    out = str(tmp_path / "o.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(tmp_path / "f"), str(tmp_path / "w"),
+                        out, str(tmp_path / "o.csv")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    k = json.load(open(out))["kernels"]
+    assert "FillFunctor" not in k                                           # outside the timed steps
+    tiny = k["dd_gemm2_kernel_tiny"]
+    assert tiny["launches_per_step"] == 3 and len(tiny["shapes"]) == 2
+    # (2 x 1000 + 3000) / 3 KB fetched (x2 corrected) + half of that written
+    want = ((2 * 1000 + 3000) / 3.0) * 1024 * 2 + ((2 * 1000 + 3000) / 3.0) * 0.5 * 1024
+    assert abs(tiny["hbm_bytes_per_launch"] - want) < 1.0
+    # the bench line's lookup reads the same structure
+    import bench
+    assert abs(bench._pmc_traffic("dd_gemm2_kernel_tiny", k) - want) < 1.0

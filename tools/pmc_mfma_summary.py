@@ -20,13 +20,24 @@ csv.field_size_limit(1 << 30)
 
 def main():
     d, out = sys.argv[1:3]
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    recs = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
-                a = acc[r["Kernel_Name"]][r["Counter_Name"]]
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
+                recs.append((int(r["Dispatch_Id"]), r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])))
+    # only the dispatches of the last `steps` denoising steps (a step ends with the cfg_ddim kernel): the tuner's
+    # and the warm-up's launches are not the population the bench line describes (tools/pmc_summary.py)
+    recs.sort()
+    ends = sorted({r[0] for r in recs if "cfg_ddim" in r[1]})
+    if len(ends) >= steps + 1:
+        lo, hi = ends[-steps - 1], ends[-1]
+        recs = [r for r in recs if lo < r[0] <= hi]
+    for _, name, cname, val in recs:
+        a = acc[name][cname]
+        a[0] += val
+        a[1] += 1
     rows = []
     for name, c in acc.items():
         if "GRBM_GUI_ACTIVE" not in c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c:
