@@ -550,7 +550,7 @@ def compact_line(full, full_path=None, limit=LINE_LIMIT):
             out["cpu_baseline"]["bf16_value"] = b
     else:
         out["cpu_baseline"] = None
-    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling"):
+    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling", "batched"):
         if full.get(k) is not None:
             out[k] = full[k]
     for k in ("view_split", "frame_split"):
@@ -562,6 +562,7 @@ def compact_line(full, full_path=None, limit=LINE_LIMIT):
                  lambda o: o.pop("tolerance", None),
                  lambda o: o["roofline"] and o["roofline"].pop("timing", None),
                  lambda o: o["cpu_baseline"] and o["cpu_baseline"].update(sample=o["cpu_baseline"]["sample"][:120]),
+                 lambda o: o.pop("batched", None),
                  lambda o: o.pop("strong_scaling", None),
                  lambda o: o["config"].pop("view_split", None) or o["config"].pop("frame_split", None),
                  lambda o: o["config"].update(workload=o["config"].get("workload", "")[:80])):
@@ -757,6 +758,10 @@ def main():
     ap.add_argument("--challenge-tiles", default="",
                     help="comma-separated GEMM tile ids added after the tracked table was written: every entry's incumbent is "
                          "timed against them once (3 %% to win) and the table is written back to --tune-cache")
+    ap.add_argument("--batched-scenes", type=int, default=2,
+                    help="N = 1, default workload only: ALSO time this many scenes per GPU in one batch (headline dtype, no "
+                         "roofline leg) and report it as `batched` — the serving-throughput form of the same step (value "
+                         "stays the one-scene configuration SURVEY §8d names); 0 = off")
     ap.add_argument("--strong-leg", default="auto", choices=["auto", "off"],
                     help="N > 1 in the default scene-sharded mode: after the weak-scaling measurement rank 0 runs ONE scene "
                          "over all N GPUs (--parallelism view-split) as a fresh child job with a hard timeout and reports it "
@@ -813,6 +818,18 @@ def main():
     if not args.single_dtype and args.parallelism == "scenes":
         other = measure(args, other_name, device, dist, world, rank, backend, False)
 
+    batched = None
+    if (world == 1 and args.parallelism == "scenes" and args.scenes == 1 and args.frames == 1 and args.batched_scenes > 1
+            and not args.fp8_weights and not args.lora_rank and not args.no_graph):
+        bargs = argparse.Namespace(**vars(args))
+        bargs.scenes = args.batched_scenes
+        try:
+            br = measure(bargs, args.dtype, device, dist, world, rank, backend, False)
+            batched = {"scenes_per_gpu": bargs.scenes, "value": args.steps * bargs.scenes / br["elapsed"],
+                       "unit": "scene-steps/s", "ms_per_scene_step": br["elapsed"] / args.steps * 1e3 / bargs.scenes,
+                       "outputs_finite": br["finite"]}
+        except Exception as e:                                     # informative leg: never fail the bench on it
+            batched = {"scenes_per_gpu": bargs.scenes, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     want_strong = world > 1 and args.parallelism == "scenes" and args.strong_leg == "auto"
     if dist is not None:                       # the weak-scaling job is over: every rank leaves the group and frees its GPU memory
         torch.cuda.empty_cache()
@@ -888,6 +905,8 @@ def main():
         out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
     if strong is not None:
         out["strong_scaling"] = strong
+    if batched is not None:
+        out["batched"] = batched
     path = _write_full_report(out, "%s_n%d_%s" % (args.dtype, world, args.parallelism))
     line = json.dumps(compact_line(out, path))
     assert len(line) < LINE_LIMIT, len(line)
