@@ -992,19 +992,23 @@ def silu(x, out=None):
 
 
 def nchw_to_nhwc(x, c_pad=None, views=1):
-    """(m, c, h, views * w) contiguous -> (m * views * h * w, c_pad) NHWC rows with zero-padded channels (c_pad rounded up to
-    a multiple of 8); views > 1 also splits a panorama into its views (map_embedder.py:116-125).  One LDS-tiled launch,
-    both sides coalesced (csrc/tokens.hip)."""
+    """(m, c, h, views * w) contiguous -> (m * views * h * w, c_pad) NHWC rows with zero-padded channels (default: no
+    padding); views > 1 also splits a panorama into its views (map_embedder.py:116-125).  c_pad % 8 == 0: one LDS-tiled
+    launch, both sides coalesced (csrc/tokens.hip); other widths (views == 1 only): the element-wise kernel."""
     lib = _native.load()
     _need_gpu(x)
     m, c, h, wt = x.shape
     if wt % views:
         raise ValueError("nchw_to_nhwc: width %d is not %d views" % (wt, views))
-    c_pad = (c if c_pad is None else c_pad)
-    c_pad = (c_pad + 7) // 8 * 8
+    c_pad = c if c_pad is None else c_pad
     x = x.contiguous()
     out = torch.empty((m * views * h * (wt // views), c_pad), dtype=x.dtype, device=x.device)
-    rc = lib.dd_nchw_to_nhwc_views(_ptr(x), _ptr(out), m, c, h, wt // views, views, c_pad, _dt(x), _stream())
+    if c_pad % 8 == 0:
+        rc = lib.dd_nchw_to_nhwc_views(_ptr(x), _ptr(out), m, c, h, wt // views, views, c_pad, _dt(x), _stream())
+    elif views == 1:
+        rc = lib.dd_nchw_to_nhwc(_ptr(x), _ptr(out), m, c, h * wt, c_pad, _dt(x), _stream())
+    else:
+        raise ValueError("nchw_to_nhwc: a view split needs c_pad % 8 == 0")
     _native.check(rc, "nchw_to_nhwc")
     return out
 
