@@ -352,7 +352,11 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
             grp = pair_groups[plan.shard]
             kw.update({"cfg_half": plan.half, "cfg_exchange": lambda e: cfg_all_gather(e, grp)})
         pairs = world                                  # the whole job advances ONE scene
-        graph = graph and os.environ.get("DD_VIEW_SPLIT_GRAPH") == "1"     # p2p inside a captured graph: opt-in
+        # "segments" (default): the step as a chain of HIP-graph segments with the exchanges between them
+        # (parallel.SegmentedGraph); "single": ONE graph with the point-to-point operations captured inside it (RCCL
+        # only; never run on >= 2 GPUs in this build's reach); "off": eager launches
+        graph = graph and args.shard_graph != "off"
+        kw["segmented_graph"] = args.shard_graph != "single"
         shard_desc = "views %s of CFG half %s" % (plan.local, "both" if plan.half is None else plan.half)
         # bytes this rank sends / receives per UNet forward: 16 transformer blocks = 5 x (1400 tokens, 320 ch),
         # 5 x (350, 640), 5 x (91, 1280), 1 x (28, 1280); K and V of every exchanged view-instance
@@ -383,7 +387,7 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
             grp = pair_groups[rank // 2]
             kw.update({"cfg_half": rank % 2, "cfg_exchange": lambda e: cfg_all_gather(e, grp)})
         pairs = world
-        graph = graph and os.environ.get("DD_VIEW_SPLIT_GRAPH") == "1"     # collectives inside a captured graph: opt-in
+        graph = graph and args.shard_graph == "single"                     # collectives inside ONE captured graph: opt-in
         shard_desc = "frames %s" % plan.local
         sent = recv = 0
         for nblk, (ntok, ch) in ((5, (1400, 320)), (5, (350, 640)), (5, (91, 1280)), (1, (28, 1280))):
@@ -489,6 +493,8 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
                             r["achieved"], r["unit"], r["frac"]))
     del den, unet, cns
     torch.cuda.empty_cache()
+    if graph and args.parallelism == "view-split":
+        graph = "segments" if kw.get("segmented_graph") else "single"
     return {"elapsed": elapsed, "finite": finite, "roofline": roofline, "graph": graph, "pairs": pairs,
             "shard": shard_desc, "shard_msg": shard_msg}
 
@@ -635,13 +641,14 @@ def _last_json_line(text):
     return None
 
 
-def _strong_child(world, args, weak_ms_per_step, timeout_s, extra_env=None):
+def _strong_child(world, args, weak_ms_per_step, timeout_s, shard_graph):
     argv = ["--gpus", str(world), "--parallelism", "view-split", "--steps", str(args.steps), "--warmup", str(args.warmup),
-            "--dtype", args.dtype, "--single-dtype", "--no-roofline", "--no-cpu-baseline", "--strong-leg", "off"]
+            "--dtype", args.dtype, "--single-dtype", "--no-roofline", "--no-cpu-baseline", "--strong-leg", "off",
+            "--shard-graph", shard_graph]
     if args.plumbing_check:
         argv.append("--plumbing-check")
     t0 = time.perf_counter()
-    rc, so, se = _run_child_job(world, argv, timeout_s, extra_env)
+    rc, so, se = _run_child_job(world, argv, timeout_s)
     took = round(time.perf_counter() - t0, 1)
     line = _last_json_line(so)
     if rc is None:
@@ -652,9 +659,12 @@ def _strong_child(world, args, weak_ms_per_step, timeout_s, extra_env=None):
         return {"plumbing_check": True, "n_gpus": line.get("n_gpus"), "seconds": took}
     vs = (line.get("config") or {}).get("view_split") or {}
     ms = line.get("ms_per_step")
+    got = (line.get("config") or {}).get("hip_graph")
+    if shard_graph != "off" and got != shard_graph:
+        return {"error": "asked for --shard-graph %s, ran %s (capture fell back)" % (shard_graph, got), "seconds": took}
     return {"value": line.get("value"), "ms_per_step": ms,
             "speedup_vs_one_gpu": (round(weak_ms_per_step / ms, 3) if ms and weak_ms_per_step else None),
-            "outputs_finite": line.get("outputs_finite"), "hip_graph": (line.get("config") or {}).get("hip_graph"),
+            "outputs_finite": line.get("outputs_finite"), "hip_graph": got,
             "message_bytes_per_forward": vs.get("rank0_sent_bytes_per_forward"), "views_per_rank": vs.get("views_per_rank"),
             "seconds": took}
 
@@ -662,28 +672,27 @@ def _strong_child(world, args, weak_ms_per_step, timeout_s, extra_env=None):
 def strong_scaling_leg(world, args, weak_ms_per_step):
     """ONE scene over all `world` GPUs (view split: CFG halves x view shards, neighbour-view K/V point to point in
     every transformer block + the CFG pair all-gather) as fresh CHILD jobs; returns the `strong_scaling` object of the
-    bench line.  Two children, each under its own share of the time budget: first with eager launches (the form every
-    test covers), then with the step captured in a HIP graph including its RCCL point-to-point operations
-    (DD_VIEW_SPLIT_GRAPH=1) — never run on >= 2 GPUs in this build's reach, so its failure or timeout only costs that
-    entry.  `speedup_vs_one_gpu` compares with the time a single GPU needs for one scene IN THIS RUN (the scene-sharded
-    measurement: every rank denoised its own scene alone)."""
+    bench line.  Three children, each under a third of the time budget: eager launches (the form every test covers);
+    HIP-graph SEGMENTS with the exchanges between them (parallel.SegmentedGraph: verified replay == eager over gloo on a
+    shared GPU); ONE graph with the RCCL point-to-point operations captured inside it — never run on >= 2 GPUs in this
+    build's reach, so its failure or timeout only costs that entry.  `speedup_vs_one_gpu` compares with the time a
+    single GPU needs for one scene IN THIS RUN (the scene-sharded measurement: every rank denoised its own scene)."""
     out = {"mode": "view-split", "unit": "steps/s (one scene on %d GPUs)" % world}
-    eager = _strong_child(world, args, weak_ms_per_step, args.strong_timeout * 0.5)
-    if eager.get("plumbing_check"):
-        return dict(out, **eager)
-    out["eager"] = eager
-    graph = _strong_child(world, args, weak_ms_per_step, args.strong_timeout * 0.5, {"DD_VIEW_SPLIT_GRAPH": "1"})
-    if "error" not in graph and not graph.get("hip_graph"):
-        graph = {"error": "capture fell back to eager launches", "seconds": graph.get("seconds")}
-    out["graph"] = graph
-    ok = [r for r in (eager, graph) if "error" not in r and r.get("outputs_finite")]
+    legs = {}
+    for name in ("off", "segments", "single"):
+        legs[name] = _strong_child(world, args, weak_ms_per_step, args.strong_timeout / 3.0, name)
+        if legs[name].get("plumbing_check"):
+            return dict(out, **legs[name])
+    out.update({"eager": legs["off"], "segments": legs["segments"], "single_graph": legs["single"]})
+    ok = {k: r for k, r in legs.items() if "error" not in r and r.get("outputs_finite")}
     if ok:
-        best = max(ok, key=lambda r: r["value"])
+        name = max(ok, key=lambda k: ok[k]["value"])
+        best = ok[name]
         out.update({k: best[k] for k in ("value", "ms_per_step", "speedup_vs_one_gpu", "views_per_rank",
                                          "message_bytes_per_forward")})
-        out["best"] = "graph" if best is graph else "eager"
+        out["best"] = {"off": "eager", "segments": "segments", "single": "single_graph"}[name]
     else:
-        out["error"] = "no finite result: eager %s; graph %s" % (eager.get("error"), graph.get("error"))
+        out["error"] = "no finite result: " + "; ".join("%s: %s" % (k, r.get("error")) for k, r in legs.items())
     out["verified_on_multi_gpu_hardware"] = bool(ok) and not os.environ.get("DD_BENCH_SHARE_GPU")
     return out
 
@@ -780,6 +789,10 @@ def main():
     ap.add_argument("--challenge-tiles", default="",
                     help="comma-separated GEMM tile ids added after the tracked table was written: every entry's incumbent is "
                          "timed against them once (3 %% to win) and the table is written back to --tune-cache")
+    ap.add_argument("--shard-graph", default=os.environ.get("DD_SHARD_GRAPH", "segments"), choices=["segments", "single", "off"],
+                    help="view-split: how the sharded step is launched — 'segments' (default): HIP-graph segments with the "
+                         "neighbour K/V exchanges between them; 'single': one graph with the point-to-point operations inside "
+                         "(RCCL only); 'off': eager.  frame-split: 'single' or eager")
     ap.add_argument("--batched-scenes", type=int, default=2,
                     help="N = 1, default workload only: ALSO time this many scenes per GPU in one batch (headline dtype, no "
                          "roofline leg) and report it as `batched` — the serving-throughput form of the same step (value "
@@ -788,7 +801,7 @@ def main():
                     help="N > 1 in the default scene-sharded mode: after the weak-scaling measurement rank 0 runs ONE scene "
                          "over all N GPUs (--parallelism view-split) as a fresh child job with a hard timeout and reports it "
                          "as `strong_scaling` in the same line (never a second line, never a hang)")
-    ap.add_argument("--strong-timeout", type=float, default=float(os.environ.get("DD_STRONG_TIMEOUT", "240")),
+    ap.add_argument("--strong-timeout", type=float, default=float(os.environ.get("DD_STRONG_TIMEOUT", "300")),
                     help="seconds the strong-scaling child job may take before its process group is killed")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher / rendezvous check only (gloo, no GPU call, no measurement): prints n_gpus")

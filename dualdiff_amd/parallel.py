@@ -203,6 +203,59 @@ def view_split_groups(world, cfg_split=True):
     return halves, cfg_pair_groups(world)
 
 
+class SegmentedGraph:
+    """A step recorded as a CHAIN of HIP graphs with eager hand-offs between them (round 4).
+
+    The view-split step needs the neighbour views' K/V from other ranks in each of the 16 UNet transformer blocks.  The
+    exchange cannot live inside a captured graph on every backend (gloo stages through the host; RCCL point-to-point
+    inside a capture has never run on >= 2 GPUs in this build's reach), and launching the ~800 kernels of the step
+    eagerly costs more host time than a 1-3-view shard's device time.  So the step is captured in SEGMENTS: every
+    exchange ends the current capture (`cut`), is stored as a callable, runs once (all ranks record in lock step), and
+    the next capture begins in the same memory pool — tensors keep their addresses, a replay is graph, exchange, graph,
+    ... in recording order: 17 graph launches + 16 exchanges instead of ~800 kernel launches per step.
+    Side streams forked inside the step must be joined before a cut (the pipeline joins the ControlNet branches
+    before the UNet encoder in this mode)."""
+
+    def __init__(self):
+        self.graphs, self.between = [], []
+        self.recording = False
+        self._pool = None
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._pool)
+        self.graphs.append(g)
+
+    def record(self, fn):
+        """Records fn() on the CURRENT (non-default) stream; `cut` calls inside fn split the recording."""
+        self._pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize()
+        self.recording = True
+        try:
+            self._begin()
+            fn()
+            self.graphs[-1].capture_end()
+        finally:
+            self.recording = False
+        return self
+
+    def cut(self, fn):
+        self.graphs[-1].capture_end()
+        self.between.append(fn)
+        fn()
+        self._begin()
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.between):
+                self.between[i]()
+
+    @property
+    def segments(self):
+        return len(self.graphs)
+
+
 class ViewShard:
     """What a view-sharded model needs at run time: the static plan, the exchange callable (HaloExchange,
     or an in-process stand-in for tests) and cached device-side kv_batch_maps.  Installed on every
@@ -210,8 +263,20 @@ class ViewShard:
 
     def __init__(self, plan, exchange=None):
         self.plan = plan
-        self.exchange = exchange if exchange is not None else HaloExchange(plan)
+        self._exchange = exchange if exchange is not None else HaloExchange(plan)
         self._maps = {}
+        self.segmenter = None        # a SegmentedGraph while the step is being recorded / replayed in segments
+
+    def exchange(self, kv):
+        """Fills the remote slots of `kv`.  While a SegmentedGraph records the step, the exchange is a CUT: the current
+        HIP-graph segment ends, the exchange runs eagerly (now, and between the segments at every replay, on the same
+        `kv` buffer — graph memory keeps its address), the next segment begins."""
+        seg = self.segmenter
+        if seg is not None and seg.recording:
+            seg.cut(lambda: self._exchange(kv))
+        else:
+            self._exchange(kv)
+        return kv
 
     @property
     def n_local(self):

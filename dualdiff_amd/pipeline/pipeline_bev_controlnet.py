@@ -49,7 +49,7 @@ class BEVDenoiser:
     def __init__(self, unet, controlnets: List, guidance_scale=2.0, num_inference_steps=50,
                  conditioning_scale=1.0, hoist_invariant=False, use_graph=True, use_aug_text=False,
                  parallel_branches=True, cfg_half: Optional[int] = None, cfg_exchange=None,
-                 sampler="ddim", view_shard=None, frame_shard=None):
+                 sampler="ddim", view_shard=None, frame_shard=None, segmented_graph=True):
         self.unet = unet
         self.controlnets = list(controlnets)
         self.guidance_scale = float(guidance_scale)
@@ -70,6 +70,10 @@ class BEVDenoiser:
             self.num_inference_steps = len(self.timesteps)
         self._graph = None
         self._prepared = None
+        self._segmented = False
+        # view split + use_graph: record the step as graph SEGMENTS with the exchanges between them (default) instead of
+        # one graph that would have to contain the point-to-point operations
+        self.segmented_graph = bool(segmented_graph)
         # The ControlNet branches and the UNet encoder (conv_in + down + mid) are mutually
         # independent until the residual add: run them on separate HIP streams (fork / join inside
         # the captured graph) so the small deep-level kernels of one fill the CUs the others leave idle.
@@ -215,9 +219,13 @@ class BEVDenoiser:
                                                           self.prompt_embeds, self.use_aug_text)
             run_branch(0, tok0)                                          # fork branch 0 once its tokens exist
             prep0 = tok0
+            if self._segmented:                                          # segments cannot end with forked work in flight:
+                for s in self._side:                                     # the branches run beside each other, the UNet after
+                    main.wait_stream(s)
             state = self.unet.encode_nhwc(x8, m, h, w, self.t_dev, prep0["ctx2d"], prep0["lc"])
-            for s in self._side:                                         # join
-                main.wait_stream(s)
+            if not self._segmented:
+                for s in self._side:                                     # join
+                    main.wait_stream(s)
             if n == 1:
                 down = [r[0] for r in results[0][:-1]]
                 mid = results[0][-1][0]
@@ -256,15 +264,30 @@ class BEVDenoiser:
         self._step_body()
         torch.cuda.synchronize()
         restore()
-        g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self._step_body()                                            # warm-up on the capture stream
-            torch.cuda.synchronize()
-            restore()
-            with torch.cuda.graph(g, stream=s):
-                self._step_body()
+        if self.view_shard is not None and self.segmented_graph:
+            # view split: a chain of graph segments with the neighbour K/V exchanges between them (parallel.SegmentedGraph)
+            from ..parallel import SegmentedGraph
+            self._segmented = True
+            g = SegmentedGraph()
+            with torch.cuda.stream(s):
+                self._step_body()                                        # warm-up in the segmented stream layout
+                torch.cuda.synchronize()
+                restore()
+                self.view_shard.segmenter = g
+                try:
+                    g.record(self._step_body)
+                finally:
+                    self.view_shard.segmenter = None
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s):
+                self._step_body()                                        # warm-up on the capture stream
+                torch.cuda.synchronize()
+                restore()
+                with torch.cuda.graph(g, stream=s):
+                    self._step_body()
         torch.cuda.current_stream().wait_stream(s)
         restore()
         self._graph = g
