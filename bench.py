@@ -793,7 +793,7 @@ def main():
                     help="view-split: how the sharded step is launched — 'segments' (default): HIP-graph segments with the "
                          "neighbour K/V exchanges between them; 'single': one graph with the point-to-point operations inside "
                          "(RCCL only); 'off': eager.  frame-split: 'single' or eager")
-    ap.add_argument("--batched-scenes", type=int, default=2,
+    ap.add_argument("--batched-scenes", type=int, default=4,
                     help="N = 1, default workload only: ALSO time this many scenes per GPU in one batch (headline dtype, no "
                          "roofline leg) and report it as `batched` — the serving-throughput form of the same step (value "
                          "stays the one-scene configuration SURVEY §8d names); 0 = off")
