@@ -527,3 +527,45 @@ def test_foreign_checkpoint_import_forward(gpu, tmp_path):
         with storage_emulation(ora, dtype):
             emul = ora(x, t, encoder_hidden_states=ctx).sample
     assert report("foreign checkpoint unet eps", y, ref, dtype, rec, emul) <= 1.0, rec
+
+
+@pytest.mark.parametrize("case", ["no_boxes", "all_boxes_masked", "one_box"])
+def test_controlnet_forward_box_edge_cases(cnet_case, case):
+    """Edge cases of the box-token path (unet_addon_rawbox.py:852-896, bbox_embedder.py:164-203): `bboxes_3d_data=None` (the
+    context is [cam | text] only), every box masked out (all box tokens are the learned null token), a single box — HIP vs
+    the oracle on the panorama branch, fp16, same floor-based bound as the main ControlNet case."""
+    dtype = torch.float16
+    inp, refs = cnet_case
+    sd = refs[False][0]
+    boxes = inp["boxes_bg"]
+    if case == "no_boxes":
+        boxes = None
+    elif case == "all_boxes_masked":
+        boxes = dict(boxes, masks=torch.zeros_like(boxes["masks"]))
+    else:
+        boxes = {k: v[:, :, :1].contiguous() for k, v in boxes.items()}
+    ora = R.BEVControlNetModel(use_occ_3d=False).eval()
+    ora.load_state_dict(sd)
+
+    def run():
+        return ora(inp["sample"], inp["timestep"], inp["camera_param"], boxes, inp["text"], inp["cond_bg"],
+                   conditioning_scale=0.75)
+    with torch.no_grad():
+        rdown, rmid, rctx = run()
+        with storage_emulation(ora, dtype):
+            edown, emid, ectx = run()
+    net = _make_cnet(sd, False, dtype)
+    d = _to_dev(inp, dtype)
+    with torch.no_grad():
+        down, mid, ctx = net(d["sample"], d["timestep"], d["camera_param"], None if boxes is None else _to_dev(boxes, dtype),
+                             d["text"], d["cond_bg"], conditioning_scale=0.75, return_dict=False, use_aug_text=False)
+    want_lc = 1 + LTXT + (0 if boxes is None else boxes["bboxes"].shape[2])
+    assert ctx.shape == (12, want_lc, 768) == tuple(rctx.shape)
+    rec = []
+    errs = [report("cnet %s ctx tokens" % case, ctx, rctx, dtype, rec, ectx),
+            report("cnet %s down[0]" % case, down[0], rdown[0], dtype, rec, edown[0]),
+            report("cnet %s down[11]" % case, down[11], rdown[11], dtype, rec, edown[11]),
+            report("cnet %s mid" % case, mid, rmid, dtype, rec, emid)]
+    assert max(errs) <= 1.0, rec
+    if case == "all_boxes_masked":          # every box token is the same learned null token
+        assert torch.equal(ctx[:, 1 + LTXT], ctx[:, -1]) and torch.equal(ctx[0, 1 + LTXT], ctx[7, 1 + LTXT])
