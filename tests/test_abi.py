@@ -63,3 +63,20 @@ def test_ops_fail_loudly_on_cpu_tensors():
     from dualdiff_amd import ops
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.add(torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.float16))
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/dualdiff_hip.h must compile as C99 and as C++17 on its own (no torch / HIP types
+    in the signatures, dd_stream_t is a void pointer)."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "dualdiff_hip.h")
+    for cc, flags in (("gcc", ["-std=c99", "-x", "c"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not installed")
+        r = subprocess.run([cc] + flags + ["-fsyntax-only", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    import re
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)                          # declarations without comments
+    assert "torch" not in code.lower() and "at::" not in code and "hipStream_t" not in code
+    assert "typedef void* dd_stream_t" in code and "#include <stdint.h>" in code
