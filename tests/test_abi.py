@@ -80,3 +80,38 @@ def test_header_is_plain_c():
     code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)                          # declarations without comments
     assert "torch" not in code.lower() and "at::" not in code and "hipStream_t" not in code
     assert "typedef void* dd_stream_t" in code and "#include <stdint.h>" in code
+
+
+def test_c_host_links_and_validates(tmp_path):
+    """A C host (what INTEGRATION.md §4 shows) compiled with gcc against include/dualdiff_hip.h and the built library:
+    version / descriptor-size handshake and argument validation run without a GPU (no launch happens before them)."""
+    import shutil
+    import subprocess
+    from dualdiff_amd import _build
+    if shutil.which("gcc") is None or not os.path.exists(_build.lib_path()):
+        pytest.skip("gcc or the built library missing")
+    src = tmp_path / "host.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "dualdiff_hip.h"
+int main(void) {
+  dd_gemm_desc d; memset(&d, 0, sizeof d);
+  if (dd_abi_version() != DD_ABI_VERSION) return 10;
+  if (dd_desc_size(0) != (int64_t)sizeof(dd_gemm_desc) || dd_desc_size(1) != (int64_t)sizeof(dd_attn_desc)) return 11;
+  if (dd_desc_size(4) != (int64_t)sizeof(dd_box_tokens_desc) || dd_desc_size(99) != -1) return 12;
+  if (dd_gemm(&d, 0) != DD_ERR_BAD_ARG) return 13;                 /* null pointers: rejected before any launch */
+  if (strcmp(dd_target_arch(), "gfx950") != 0) return 14;
+  printf("%s\n", dd_error_string(DD_ERR_UNSUPPORTED));
+  return 0;
+}
+""")
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_build.lib_path())
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-ldualdiff_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert "unsupported" in r.stdout
