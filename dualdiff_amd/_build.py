@@ -54,7 +54,10 @@ def build_native(force=False, verbose=True):
         return lib_path()
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+    # -O2, not -O3: same arithmetic, 0.5 % smaller code and +0.4 % on the step in three alternating same-box pairs (86.49 /
+    # 86.55 / 86.56 against 86.19 / 86.17 / 86.09; -Os the same; profiles/r04_experiments.txt #5) — the kernels' hot loops are
+    # unrolled by hand, what -O3 adds is code around them that every launch fetches cold
+    flags = ["--offload-arch=" + ARCH, "-O2", "-std=c++17", "-fPIC", "-Wno-unused-value",
              "-DNDEBUG"] + os.environ.get("DD_HIP_DEFINES", "").split()
 
     def compile_one(src):
