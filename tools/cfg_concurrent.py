@@ -27,6 +27,9 @@ def timed(fn, steps, warm=5):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    # streams per half chain: 3 (the production fork / join: 6 in all, MORE than the 4 hardware queues, which the command
+    # processor then time-slices — profiles/r03_hw_queues.txt) or 1 (serial branches: 2 in all)
+    par = (sys.argv[2] if len(sys.argv) > 2 else "3") == "3"
     dev, dtype = torch.device("cuda:0"), torch.float16
     torch.cuda.set_device(dev)
     unet, cns = bench.build_models(dtype, dev, frames=1, fp8=False, lora_rank=0)
@@ -43,7 +46,7 @@ def main():
         ref = den.latents.float().clone()
 
         box = {}
-        halves = [BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50, use_graph=False,
+        halves = [BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50, use_graph=False, parallel_branches=par,
                               cfg_half=h, cfg_exchange=lambda e: box["eps2"]) for h in (0, 1)]
         for d in halves:
             d.set_inputs(*inputs)
@@ -104,6 +107,25 @@ def main():
                 main_s.wait_stream(lanes[k])
             combine()
 
+        if len(sys.argv) > 3 and sys.argv[3] == "onegraph":
+            # both chains inside ONE captured graph: a single fork / join (nested forks — a forked chain forking its
+            # ControlNet branches again — crash hipGraphInstantiate on this ROCm, so this form needs 1 stream per chain)
+            s1 = torch.cuda.Stream()
+            s1.wait_stream(torch.cuda.current_stream())
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s1):
+                body()
+                torch.cuda.synchronize()
+                restore()
+                with torch.cuda.graph(g1, stream=s1):
+                    body()
+            torch.cuda.current_stream().wait_stream(s1)
+            restore()
+
+            def step2(i):                                          # noqa: F811
+                set_step(i % 50)
+                g1.replay()
+
         for i in range(2):
             step2(i)
         got = a.latents.float()
@@ -113,6 +135,7 @@ def main():
         restore()
         ms_eager = timed(lambda i: (set_step(i % 50), body()), 10, warm=2)
     print("one chain, 12 view-instances : %.3f ms/step  %.2f steps/s" % (ms_one, 1e3 / ms_one))
+    print("streams per half chain: %d" % (3 if par else 1))
     print("two concurrent half chains   : %.3f ms/step  %.2f steps/s   (latents after 2 steps vs one chain: rel-L2 %.2e)"
           % (ms_two, 1e3 / ms_two, err))
     print("two half chains, eager       : %.3f ms/step" % ms_eager)
