@@ -1134,6 +1134,272 @@ void dd_gemm2_kernel(const GemmParams p) {
 }
 
 // =============================================================================================
+// Kernel family 2p (round 5): the LDS-DMA ring with an UN-SERIALISED K-step.  Dense GEMMs only.
+//
+// dd_gemm2_kernel runs every K-step as the serial chain  vmcnt wait -> barrier -> DMA issue -> fragment reads ->
+// MFMAs: with one wave per SIMD (every dominant shape: <= 256 workgroups) nothing overlaps that chain and the matrix
+// pipe is busy 192 of ~800 cycles (profiles/r04_gemm2_timeline.txt).  Here the fragments of K-step
+// c+1 are read while the MFMAs of K-step c run, in two HALVES so that no second register set is needed:
+//
+//   barrier(c)  |  MFMAs on the ks=0 fragments of c   (the DMAs of stage c+D are issued between them)
+//               |  ds_reads of the ks=0 fragments of c+1  ||  MFMAs on the ks=1 fragments of c
+//               |  ds_reads of the ks=1 fragments of c+1  ||  (next step's wait + barrier + first MFMAs)
+//
+// The barrier at the top of step c therefore certifies stage c+1 (not c), and the first MFMA after it never waits
+// for LDS.  TIGHT (NSTAGE <= 3): the DMA of step c refills the slot of stage c itself, whose last fragment reads
+// (ks=1, issued at the end of step c-1) every wave retires with lgkmcnt(0) before the barrier; NSTAGE >= 4: it refills
+// the slot of stage c-1, and the only LDS wait of a step is the compiler's counted one in front of the MFMAs.
+// Same arithmetic in the same order per accumulator as dd_gemm2_kernel -> bit-identical results.
+// No persistent walk (the epilogue's stores would count in the vmcnt window of the next tile's stages), no LayerNorm
+// fold, no conv: those stay with dd_gemm2_kernel.
+// =============================================================================================
+template <int WM, int WN, int TM, int TN, int NSTAGE>
+constexpr int gemm3_min_blocks() {             // two workgroups per CU where two rings fit the LDS (<= 256 registers per wave)
+  return (WM * WN == 4 && TM * TN <= 8 && 2 * NSTAGE * (WM * TM + WN * TN) * 16 * BK * 2 <= 160 * 1024) ? 2 : 1;
+}
+
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool GEGLU>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (gemm3_min_blocks<WAVES_M, WAVES_N, TM, TN, NSTAGE>()))
+void dd_gemm3_kernel(const GemmParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 16;
+  constexpr int BN = WAVES_N * TN * 16;
+  constexpr int BN_OUT = GEGLU ? BN / 2 : BN;
+  constexpr int XI = BM / 8 / NW;                 // DMA wave-instructions (8 rows x 128 B) per wave
+  constexpr int WI = BN / 8 / NW;
+  constexpr int LPS = XI + WI;                    // DMA instructions per thread per stage
+  constexpr int STAGE = (BM + BN) * BK;           // elements per ring slot
+  constexpr bool TIGHT = NSTAGE <= 3;
+  constexpr int D = TIGHT ? NSTAGE : NSTAGE - 1;  // the DMA of step c carries stage c + D
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
+  static_assert(NW % 2 == 0, "swizzle must not depend on the instruction index");
+  static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 8 && D >= 2, "NSTAGE");
+  static_assert((D - 1) * LPS <= 63, "vmcnt is a 6-bit counter");
+
+#ifdef DD_DBG_STAMP
+  uint64_t dbg_t[6];
+  const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  DD_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* ring = reinterpret_cast<T*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm_i = tile / p.tiles_n;
+  const int block_m0 = tm_i * BM;
+  const int block_n0 = (tile - tm_i * p.tiles_n) * BN_OUT;
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.k, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // DMA mapping as in dd_gemm2_kernel: instruction j of this wave fills tile rows (j*NW + wave)*8 .. +7; lane l
+  // writes row (l >> 3), chunk position (l & 7); logical chunk = position ^ ((row >> 1) & 7)
+  const int lrow = lane >> 3;
+  const int lc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const uint32_t lcb = (uint32_t)lc * 16u;
+
+  uint32_t wv[WI];
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int R = (j * NW + wave) * 8 + lrow;
+    const int wvi = R / (TN * 16);
+    const int rho = R % (TN * 16);
+    const int tn = rho >> 4, r = rho & 15;
+    int n_glob;
+    if (GEGLU) {
+      constexpr int TH = TN / 2;
+      const int t = tn % TH;
+      const int col = block_n0 + wvi * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
+      n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
+    } else {
+      const int col = block_n0 + wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
+      n_glob = (col < p.n) ? col : -1;
+    }
+    wv[j] = n_glob >= 0 ? (uint32_t)n_glob * (uint32_t)p.k * 2u + lcb : DD_OOB;
+  }
+  uint32_t xe[XI], xe2[XI];
+#pragma unroll
+  for (int j = 0; j < XI; ++j) {
+    const int r = block_m0 + (j * NW + wave) * 8 + lrow;
+    const bool rv = r < p.rows;
+    xe[j] = rv ? (uint32_t)r * (uint32_t)p.lda * 2u + lcb : DD_OOB;
+    xe2[j] = rv ? (uint32_t)r * (uint32_t)p.lda2 * 2u + lcb : DD_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
+
+  // Issue cursor (all scalar).  The activation source is `a` for K < k1 and `a2` behind it (the up path's concat); the
+  // switch is ONE scalar branch without a DMA inside, taken at most once per workgroup and placed behind the K-step's
+  // schedule (a branch around the DMAs would cut the step into separate scheduling regions).
+  int ik0 = kbeg;
+  int islot = 0;                                   // ring slot the next stage goes to
+  int kbase = 0;
+  __amdgpu_buffer_rsrc_t rs_x = rs_a;
+  auto seam = [&]() __attribute__((always_inline)) {
+    if (ik0 >= p.k1 && kbase == 0 && p.k1 < p.k) {
+#pragma unroll
+      for (int j = 0; j < XI; ++j) xe[j] = xe2[j];
+      rs_x = rs_a2;
+      kbase = p.k1;
+    }
+  };
+  seam();
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    T* xs = ring + islot * STAGE;
+    T* ws = xs + BM * BK;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], (uint32_t)ik0 * 2u, ws + (j * NW + wave) * 8 * BK);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) bdma16(rs_x, xe[j], (uint32_t)(ik0 - kbase) * 2u, xs + (j * NW + wave) * 8 * BK);
+    ik0 += BK;
+    islot = islot + 1 == NSTAGE ? 0 : islot + 1;
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fswz = (lane >> 1) & 7;
+  const int fchunk = lane >> 4;
+  const int cofs0 = ((fchunk + 0) ^ fswz) << 3, cofs1 = ((fchunk + 4) ^ fswz) << 3;
+  const T* xbase = ring + (wave_m * TM * 16 + frow) * BK;
+  const T* wbase = ring + BM * BK + (wave_n * TN * 16 + frow) * BK;
+
+  DD_STAMP(1);
+#pragma unroll
+  for (int s0 = 0; s0 < D; ++s0)
+    if (s0 < nk) { issue_next(); seam(); }
+  DD_STAMP(2);
+
+  V8 wf[2][TN], xf[2][TM];
+  int rslot = 0;                                   // ring slot of the stage whose fragments are read next
+  auto read_half = [&](auto ks_c) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_c)::value;
+    const int cofs = ks ? cofs1 : cofs0;
+    const T* ws = wbase + rslot * STAGE + cofs;
+    const T* xs = xbase + rslot * STAGE + cofs;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK));
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK));
+  };
+  auto mfma_half = [&](auto ks_c) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+  };
+  auto wait_stages = [&](const int ahead) __attribute__((always_inline)) {      // all but the `ahead` youngest stages landed
+    if (ahead <= 0) wait_vmcnt<0>();
+    else if (ahead == 1 || D <= 2) wait_vmcnt<(D > 1 ? 1 : 0) * LPS>();
+    else if (ahead == 2 || D <= 3) wait_vmcnt<(D > 2 ? 2 : 0) * LPS>();
+    else if (ahead == 3 || D <= 4) wait_vmcnt<(D > 3 ? 3 : 0) * LPS>();
+    else if (ahead == 4 || D <= 5) wait_vmcnt<(D > 4 ? 4 : 0) * LPS>();
+    else if (ahead == 5 || D <= 6) wait_vmcnt<(D > 5 ? 5 : 0) * LPS>();
+    else wait_vmcnt<(D > 6 ? 6 : 0) * LPS>();
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  constexpr int NMF = TN * TM, NRD = TN + TM;
+
+  // stage 0 -> registers
+  wait_stages(min(D, nk) - 1);
+  __builtin_amdgcn_s_barrier();
+  read_half(K0{});
+  read_half(K1{});
+  rslot = NSTAGE > 1 ? 1 : 0;
+
+  int c = 0;
+  for (; c + D < nk; ++c) {                        // steady state: stage c+1 certified, stage c+D issued
+    wait_vmcnt<(D - 2) * LPS>();
+    if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    issue_next();
+    mfma_half(K0{});
+    read_half(K0{});
+    mfma_half(K1{});
+    read_half(K1{});
+    __builtin_amdgcn_s_setprio(0);
+    // schedule: the DMAs in the shadow of the first half's MFMAs, the ks=0 reads in the shadow of the second half's
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (i + 1 < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (NMF - 1 - LPS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - LPS, 0);
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (NMF - NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
+    seam();
+#ifdef DD_DBG_STAMP
+    if (c == 0) DD_STAMP(3);
+#endif
+  }
+  for (; c + 1 < nk; ++c) {                        // drain: nothing left to issue
+    wait_stages(min(nk - 2 - c, D - 2));
+    if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    mfma_half(K0{});
+    read_half(K0{});
+    mfma_half(K1{});
+    read_half(K1{});
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (NMF - NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
+  }
+  if (nk > 0) {                                    // last K-step: its fragments are in registers
+    __builtin_amdgcn_s_setprio(1);
+    mfma_half(K0{});
+    mfma_half(K1{});
+    __builtin_amdgcn_s_setprio(0);
+  }
+  DD_STAMP(4);
+  if (p.tile_counters) __syncthreads();            // in-launch split-K: the flag word of store_tile aliases the ring
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile,
+                               reinterpret_cast<int*>(smem));
+#ifdef DD_DBG_STAMP
+  DD_STAMP(5);
+  if (threadIdx.x == 0 && p.dbg_stamps) {
+    uint64_t* o = p.dbg_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
+    o[6] = dbg_r0;
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+// =============================================================================================
 // Kernel family 3: direct 3x3 convolution for SMALL images (14x25 and deeper: H*W <= 384).
 // The implicit-GEMM kernels stage the activation tile once per TAP (9 x per 64 input channels); at
 // the deep levels (336 / 1092 rows x 1280 channels x 29-59 MB of weights) that makes the kernel
@@ -1879,6 +2145,17 @@ constexpr TileCfg kTiles[] = {
     // (BM + BN) / (BM * BN): 0.0078 B/flop against 0.0117 for 256x128.  8 waves of 128 x 64 (32 accumulator blocks per
     // wave: one wave per SIMD pair, 2 stages of 64 KB).  Candidates for the wide GEGLU projections and the big convs.
     {50, 2, 4, 8, 4, 2, "256x256/dma2"},
+    // stages >= 100: pipelined LDS-DMA family (dd_gemm3_kernel, round 5; dense only), ring depth = stages - 100
+    {72, 2, 2, 3, 2, 103, "96x64/p3"},
+    {73, 2, 2, 3, 2, 104, "96x64/p4"},
+    {74, 2, 2, 3, 2, 105, "96x64/p5"},
+    {75, 4, 2, 3, 4, 103, "192x128/p3"},
+    {76, 2, 2, 1, 2, 104, "32x64/p4"},
+    {77, 2, 2, 2, 4, 104, "64x128/p4"},
+    {78, 2, 5, 5, 2, 103, "160x160/p3"},
+    {79, 2, 2, 4, 2, 104, "128x64/p4"},
+    {80, 2, 2, 4, 4, 103, "128x128/p3"},
+    {81, 4, 2, 4, 4, 103, "256x128/p3"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -1949,8 +2226,9 @@ Plan make_plan(const dd_gemm_desc* d) {
       const int twin[4] = {11, 17, 14, 18};
       for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == twin[ti < 4 ? ti : 3]) { ti = i; break; }
     }
-    if (kTiles[ti].stages <= 0 || !dma_ok(d)) { pl.unsupported = true; return pl; }
+    if (kTiles[ti].stages <= 0 || kTiles[ti].stages >= 100 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }
+  if (ti >= 0 && kTiles[ti].stages >= 100 && (d->conv || d->ln_out)) { pl.unsupported = true; return pl; }   // dense only
   if (d->ln_out) {                                   // LayerNorm-emitting epilogue: the 80x320 tile, one column tile
     if (d->tile > 0 && d->tile != 40) { pl.unsupported = true; return pl; }
     for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 40) ti = i;
@@ -2064,7 +2342,7 @@ Plan make_plan(const dd_gemm_desc* d) {
     // persistent walk with cross-tile prefetch (dd_gemm2_kernel): dense, one K range per tile, no epilogue that uses
     // LDS or per-tile LDS state, and a K loop at least as long as the ring.  DD_PERSIST=0 is the A/B switch.
     static const bool off = getenv("DD_PERSIST") && atoi(getenv("DD_PERSIST")) == 0;
-    pl.persist_ok = !off && !d->conv && t.stages >= 2 && split == 1 && !d->ln_colsum && !d->ln_out && nkt >= t.stages;
+    pl.persist_ok = !off && !d->conv && t.stages >= 2 && t.stages < 100 && split == 1 && !d->ln_colsum && !d->ln_out && nkt >= t.stages;
   }
   return pl;
 }
@@ -2139,6 +2417,18 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool GEGLU>
+int launch_cfg3(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
+  static_assert(smem <= 160 * 1024, "LDS");
+  auto kern = dd_gemm3_kernel<T, WM, WN, TM, TN, NSTAGE, GEGLU>;
+  static std::atomic<uint64_t> attr_done{0};
+  dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+  hipLaunchKernelGGL(kern, dim3(pl.tiles_m * pl.tiles_n, 1, pl.split), dim3(64 * WM * WN), smem, s, p);
+  return dd_check_launch();
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int NSW, int GRP = 1, bool BAND = false>
 int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -2207,11 +2497,14 @@ int launch_rp_k(const GemmParams& p, const Plan& pl, hipStream_t s) {
 
 template <typename T, bool CONV, bool GEGLU>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
+#ifndef DD_DBG_ONLY_P        // -DDD_DBG_ONLY_P: a quick-to-compile build with the pipelined family only (reading its ISA)
   if (kTiles[pl.tile_idx].stages == -2) {
     if constexpr (!CONV && !GEGLU) return launch_rp_k<T>(p, pl, s);
     return DD_ERR_UNSUPPORTED;
   }
+#endif
   switch (kTiles[pl.tile_idx].id) {
+#ifndef DD_DBG_ONLY_P
     case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
     case 39: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5, 1, true>(p, pl, s); break;
     case 33: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 8>(p, pl, s); break;
@@ -2220,6 +2513,18 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 36: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 4, 3>(p, pl, s); break;
     case 37: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 6, 3>(p, pl, s); break;
     case 38: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 6, 3>(p, pl, s); break;
+#endif
+    case 72: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false>(p, pl, s); break;
+    case 73: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 4, false>(p, pl, s); break;
+    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
+    case 75: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 3, 4, 3, GEGLU>(p, pl, s); break;
+    case 76: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false>(p, pl, s); break;
+    case 77: if constexpr (!CONV) return launch_cfg3<T, 2, 2, 2, 4, 4, GEGLU>(p, pl, s); break;
+    case 78: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
+    case 79: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 4, 2, 4, false>(p, pl, s); break;
+    case 80: if constexpr (!CONV) return launch_cfg3<T, 2, 2, 4, 4, 3, GEGLU>(p, pl, s); break;
+    case 81: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 4, 4, 3, GEGLU>(p, pl, s); break;
+#ifndef DD_DBG_ONLY_P
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
     case 14: return launch_cfg2<T, 2, 2, 2, 4, 3, CONV, GEGLU>(p, pl, s);
@@ -2251,6 +2556,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 2: if constexpr (!GEGLU) return launch_cfg<T, 2, 2, 4, 2, CONV, false>(p, pl, s); break;
     case 4: if constexpr (!GEGLU) return launch_cfg<T, 2, 2, 2, 2, CONV, false>(p, pl, s); break;
+#endif
   }
   return DD_ERR_UNSUPPORTED;
 }
@@ -2386,6 +2692,13 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
     snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d ink=%d grid=%dx%d tile=%s",
              d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, nsw, (t.id >= 37 && !band) ? 3 : 1,
              band ? "true" : "false", pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)), pl.tiles_m, pl.tiles_n, t.name);
+    return g_kname;
+  }
+  if (t.stages >= 100) {
+    snprintf(g_kname, sizeof(g_kname), "dd_gemm3_kernel<%s, %d, %d, %d, %d, %d, %s> split=%d ink=%d grid=%dx%d tile=%s",
+             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.stages - 100,
+             d->epilogue == DD_EPI_GEGLU ? "true" : "false", pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)),
+             pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol

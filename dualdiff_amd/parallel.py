@@ -227,7 +227,11 @@ class SegmentedGraph:
         self.graphs.append(g)
 
     def record(self, fn):
-        """Records fn() on the CURRENT (non-default) stream; `cut` calls inside fn split the recording."""
+        """Records fn() on the CURRENT (non-default) stream; `cut` calls inside fn split the recording.
+        If fn(), an exchange or a capture_end raises, the open capture is ENDED before the error propagates (a raw
+        capture_begin has no context manager to do it: the stream would stay in capture mode and every later launch,
+        allocation or synchronize would fail with 'operation not permitted when stream is capturing', hiding the real
+        error) and the half-recorded chain is dropped, so an eager step can follow."""
         self._pool = torch.cuda.graph_pool_handle()
         torch.cuda.synchronize()
         self.recording = True
@@ -235,9 +239,20 @@ class SegmentedGraph:
             self._begin()
             fn()
             self.graphs[-1].capture_end()
+        except BaseException:
+            self._abort()
+            raise
         finally:
             self.recording = False
         return self
+
+    def _abort(self):
+        try:
+            if self.graphs and torch.cuda.is_current_stream_capturing():
+                self.graphs[-1].capture_end()
+        except Exception:
+            pass                                  # the capture was already invalidated by the failing call
+        self.graphs, self.between = [], []
 
     def cut(self, fn):
         self.graphs[-1].capture_end()

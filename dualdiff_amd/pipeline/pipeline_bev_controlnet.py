@@ -278,6 +278,9 @@ class BEVDenoiser:
                 self.view_shard.segmenter = g
                 try:
                     g.record(self._step_body)
+                except BaseException:
+                    self._segmented = False                          # the eager step that may follow keeps the 3-stream layout
+                    raise
                 finally:
                     self.view_shard.segmenter = None
         else:

@@ -895,6 +895,81 @@ def test_gemm_persistent_walk_geglu_headmajor(ops, tile):
         check(hm, ref, dtype, "persistent head-major tile%d" % tile, 2.0)
 
 
+# ------------------------------------------------------------------ pipelined dense family (round 5) ----
+P_TILES = [72, 73, 74, 75, 76, 77, 78, 79, 80, 81]
+P_TWIN = {72: 52, 73: 52, 74: 52, 75: 44, 76: 59, 77: 24, 78: 28, 79: 23, 80: 12, 81: 20}     # same tile shape, dd_gemm2_kernel
+P_GEGLU = [75, 77, 80, 81]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", P_TILES)
+def test_gemm_pipelined_tiles(ops, dtype, tile):
+    """dd_gemm3_kernel (fragment reads of K-step c+1 under the MFMAs of K-step c): every K-loop length around the ring
+    depth (1 .. 7 steps and long), ragged row / column tails, and BIT-identity with the dd_gemm2_kernel tile of the same
+    shape (same K order per accumulator)."""
+    for (rows, n, k) in [(256, 256, 64), (200, 320, 128), (333, 192, 192), (96, 64, 256), (1092, 1280, 320),
+                         (77, 72, 384), (129, 136, 448), (336, 1280, 1280), (1400, 320, 2880)]:
+        a = rnd((rows, k), dtype, 1)
+        w = rnd((n, k), dtype, 2, 0.05)
+        b = rnd((n,), dtype, 3)
+        y = ops.gemm(a, w, b, tile=tile, split_k=1)
+        check(y, L.linear_ref(a, w, b), dtype, "gemm3 tile%d %dx%dx%d" % (tile, rows, n, k))
+        assert torch.equal(y, ops.gemm(a, w, b, tile=P_TWIN[tile], split_k=1)), "tile %d vs its gemm2 twin" % tile
+
+
+@pytest.mark.parametrize("tile", P_TILES)
+def test_gemm_pipelined_epilogues(ops, tile):
+    """Two-source A (seam inside the K range, incl. a seam that falls into the prologue stages), bias + time vector +
+    residual + alpha, accumulate into a strided view, SiLU, head-major planes, split-K (slabs + reduce launch)."""
+    dtype = torch.float16
+    rows, n, k = 12 * 91, 640, 1280
+    for k1 in (768, 64, 1216):
+        a = rnd((rows, k1), dtype, 1)
+        a2 = rnd((rows, k - k1), dtype, 11)
+        w = rnd((n, k), dtype, 2, 0.03)
+        b = rnd((n,), dtype, 3)
+        res = rnd((rows, n), dtype, 4)
+        rv = rnd((12, n), dtype, 5)
+        y = ops.gemm(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5, tile=tile, split_k=1)
+        ref = L.linear_ref(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5)
+        check(y, ref, dtype, "gemm3 concat tile%d k1=%d" % (tile, k1))
+        for split in (2, 3, 5):
+            ys = ops.gemm(a, w, b, a2=a2, res=res, rowvec=rv, rows_per_inst=91, alpha=0.5, tile=tile, split_k=split)
+            check(ys, ref, dtype, "gemm3 concat tile%d k1=%d split%d" % (tile, k1, split))
+    a = rnd((rows, k), dtype, 1)
+    buf = rnd((rows, n + 64), dtype, 6)
+    want = buf.float().cpu().clone()
+    want[:, 32:32 + n] += L.linear_ref(a, w, b)
+    ops.gemm(a, w, b, out=buf[:, 32:32 + n], accumulate=True, tile=tile, split_k=1)
+    check(buf, want, dtype, "gemm3 accumulate strided tile%d" % tile, 2.0)
+    y = ops.gemm(a, w, b, epilogue=ops.DD_EPI_SILU, tile=tile, split_k=1)
+    check(y, torch.nn.functional.silu(L.linear_ref(a, w, b)), dtype, "gemm3 silu tile%d" % tile, 2.0)
+    w3 = rnd((3 * 640, k), dtype, 7, 0.03)
+    hm = ops.gemm(a, w3, None, head_major=(80, 8, 0.25), tile=tile, split_k=1)
+    want = L.linear_ref(a, w3, None).reshape(rows, 24, 80).permute(1, 0, 2).clone()
+    want[:8] *= 0.25
+    check(hm, want, dtype, "gemm3 head-major tile%d" % tile, 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", P_GEGLU)
+def test_gemm_pipelined_geglu(ops, dtype, tile):
+    for rows, c in ((700, 640), (1092, 1280), (173, 320)):
+        a = rnd((rows, c), dtype, 1)
+        w = rnd((8 * c, c), dtype, 2, 0.05)
+        b = rnd((8 * c,), dtype, 3)
+        y = ops.gemm(a, w, b, epilogue=ops.DD_EPI_GEGLU, tile=tile)
+        check(y, L.linear_ref(a, w, b, geglu=True), dtype, "gemm3 geglu tile%d %dx%d" % (tile, rows, c), 2.0)
+        assert torch.equal(y, ops.gemm(a, w, b, epilogue=ops.DD_EPI_GEGLU, tile=P_TWIN[tile]))
+
+
+def test_gemm_pipelined_rejects_conv_and_ln(ops):
+    x = rnd((2 * 14 * 25, 64), torch.float16, 1)
+    w = rnd((64, 64, 3, 3), torch.float16, 2, 0.05)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3(x, L.pack_conv_weight(w), None, 2, 14, 25, tile=72)
+
+
 # ------------------------------------------------------------------ thin conv (condition embedder) ----
 THIN_CASES = [(8, 16, 1), (16, 16, 1), (16, 32, 2), (32, 32, 1), (8, 32, 1), (16, 32, 1), (16, 16, 2), (8, 16, 2),
               (32, 16, 1)]

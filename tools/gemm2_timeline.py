@@ -28,7 +28,7 @@ def stamps(fn):
     return st[st[:, 7] != 0]
 
 
-def show(name, rows, n, k, res=True):
+def show(name, rows, n, k, res=True, tile=0):
     x, bi = r(rows, k), r(n)
     xr = r(rows, n)
     nbuf = max(3, int(600e6 // (n * k * 2)) + 1)
@@ -36,11 +36,11 @@ def show(name, rows, n, k, res=True):
     state = {"i": 0}
 
     def hot():
-        return O.gemm(x, ws_[0], bi, res=xr if res else None)
+        return O.gemm(x, ws_[0], bi, res=xr if res else None, tile=tile, split_k=1 if tile else 0)
 
     def cold():
         state["i"] += 1
-        return O.gemm(x, ws_[state["i"] % nbuf], bi, res=xr if res else None)
+        return O.gemm(x, ws_[state["i"] % nbuf], bi, res=xr if res else None, tile=tile, split_k=1 if tile else 0)
     for _ in range(3):
         hot()
     t_hot = graph_time(hot, n=nbuf)
@@ -63,5 +63,7 @@ def show(name, rows, n, k, res=True):
                  end.max().item(), clk / 1e3, *ph, (k + 63) // 64, (ph[3] - ph[2]) / max(1, (k + 63) // 64 - 1)))
 
 
-for (rows, n, k) in ((1092, 1280, 1280), (336, 1280, 1280), (4200, 640, 640), (1092, 1280, 6400 // 5), (4200, 640, 3200), (16800, 320, 320)):
-    show("%dx%dx%d" % (rows, n, k), rows, n, k)
+TILES = [int(t) for t in os.environ.get("DD_TIMELINE_TILES", "0").split(",")]       # 0 = the tracked table's tile
+for (rows, n, k) in ((1092, 1280, 1280), (336, 1280, 1280), (4200, 640, 640), (4200, 640, 3200), (16800, 320, 320)):
+    for t in TILES:
+        show("%dx%dx%d%s" % (rows, n, k, " t%d" % t if t else ""), rows, n, k, tile=t)

@@ -5,7 +5,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 L=$R/dualdiff_amd/lib
 python3 -c "import sys; sys.path.insert(0, '$R'); from dualdiff_amd import _build; _build.build_native()" 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DNDEBUG -DDD_DBG_STAMP \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-unused-value -DNDEBUG -DDD_DBG_STAMP \
   -c $R/dualdiff_amd/csrc/gemm.hip -o /tmp/gemm_stamp.o
 OBJS=$(ls $L/obj/*.o | grep -v "/gemm.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libdd_stamp.so /tmp/gemm_stamp.o $OBJS
