@@ -37,6 +37,7 @@ struct GemmParams {
   float* partial;
   int tiles_m, tiles_n;
   uint32_t a_bytes, a2_bytes, w_bytes;   // buffer extents for the descriptor-based DMA path
+  uint32_t out_bytes, res_bytes;         // dd_gemm3_kernel's fast epilogue: extents of out / res (0 = take the general epilogue)
   int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
   int band_rows, bands; float inv_bands; // ... its BAND form: output pixels per band, bands per instance
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
@@ -1153,13 +1154,16 @@ void dd_gemm2_kernel(const GemmParams p) {
 // No persistent walk (the epilogue's stores would count in the vmcnt window of the next tile's stages), no LayerNorm
 // fold, no conv: those stay with dd_gemm2_kernel.
 // =============================================================================================
-template <int WM, int WN, int TM, int TN, int NSTAGE>
-constexpr int gemm3_min_blocks() {             // two workgroups per CU where two rings fit the LDS (<= 256 registers per wave)
-  return (WM * WN == 4 && TM * TN <= 8 && 2 * NSTAGE * (WM * TM + WN * TN) * 16 * BK * 2 <= 160 * 1024) ? 2 : 1;
+template <int WM, int WN>
+constexpr int gemm3_min_waves() {
+  // Four-wave workgroups are compiled for TWO waves per SIMD (<= 256 registers) even where only one ring fits the LDS:
+  // with the 512-register budget of one wave per SIMD hipcc moves the accumulators to AGPRs and rotates them through
+  // v_accvgpr_read / _write / _mov in every K-step of this loop (measured on the 5-slot 96x64 ring: 11.6 us against 9.5).
+  return WM * WN == 4 ? 2 : 1;
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool GEGLU>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (gemm3_min_blocks<WAVES_M, WAVES_N, TM, TN, NSTAGE>()))
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool GEGLU, bool STAG = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (gemm3_min_waves<WAVES_M, WAVES_N>()))
 void dd_gemm3_kernel(const GemmParams p) {
   using V8 = typename dd_vec<T>::v8;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -1172,11 +1176,24 @@ void dd_gemm3_kernel(const GemmParams p) {
   constexpr int STAGE = (BM + BN) * BK;           // elements per ring slot
   constexpr bool TIGHT = NSTAGE <= 3;
   constexpr int D = TIGHT ? NSTAGE : NSTAGE - 1;  // the DMA of step c carries stage c + D
+  // FAST EPILOGUE (plain T output with bias / alpha / residual / SiLU / accumulate): its operands are loaded through
+  // buffer descriptors whose extent is ZERO for an absent operand (the range check returns 0.0f: nothing is predicated,
+  // no branch per operand) and the loads are issued right behind the LAST DMA of the K loop, D-1 K-steps before the
+  // accumulators are complete — so that the epilogue starts with its operands in registers instead of paying a
+  // dependent global round trip (measured before: 1.7 us from the last MFMA to the last store of a 96x64 tile).
+  // They are ordinary loads counted in the same in-order vmcnt queue as the DMAs and YOUNGER than every DMA, so the
+  // remaining stage waits of the drain simply allow EPI more operations in flight.
+  // Register budget: 16-byte operands per lane — tiles of more than 6 (and the 10-wave tiles, 168 registers) keep the
+  // general epilogue; the accumulate target is preloaded up to 4.
+  constexpr int NG = GEGLU ? 1 : TN / 2;                           // 8-column groups per lane
+  constexpr bool FASTEPI = !GEGLU && NW <= 8 && TM * NG <= 6;
+  constexpr bool PRE_ACC = FASTEPI && TM * NG <= 4;
+  constexpr int EPI = FASTEPI ? NG + TM * NG + (PRE_ACC ? TM * NG : 0) : 0;
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
   static_assert(NW % 2 == 0, "swizzle must not depend on the instruction index");
   static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
   static_assert(NSTAGE >= 3 && NSTAGE <= 8 && D >= 2, "NSTAGE");
-  static_assert((D - 1) * LPS <= 63, "vmcnt is a 6-bit counter");
+  static_assert((D - 1) * LPS <= 63 && (D - 2) * LPS + EPI <= 63, "vmcnt is a 6-bit counter");
 
 #ifdef DD_DBG_STAMP
   uint64_t dbg_t[6];
@@ -1227,18 +1244,8 @@ void dd_gemm3_kernel(const GemmParams p) {
     }
     wv[j] = n_glob >= 0 ? (uint32_t)n_glob * (uint32_t)p.k * 2u + lcb : DD_OOB;
   }
-  uint32_t xe[XI], xe2[XI];
-#pragma unroll
-  for (int j = 0; j < XI; ++j) {
-    const int r = block_m0 + (j * NW + wave) * 8 + lrow;
-    const bool rv = r < p.rows;
-    xe[j] = rv ? (uint32_t)r * (uint32_t)p.lda * 2u + lcb : DD_OOB;
-    xe2[j] = rv ? (uint32_t)r * (uint32_t)p.lda2 * 2u + lcb : DD_OOB;
-  }
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : p.a_bytes, 0x00020000);
 
   // Issue cursor (all scalar).  The activation source is `a` for K < k1 and `a2` behind it (the up path's concat); the
   // switch is ONE scalar branch without a DMA inside, taken at most once per workgroup and placed behind the K-step's
@@ -1246,16 +1253,26 @@ void dd_gemm3_kernel(const GemmParams p) {
   int ik0 = kbeg;
   int islot = 0;                                   // ring slot the next stage goes to
   int kbase = 0;
+  int seam_k = p.a2 ? p.k1 : 0x7fffffff;           // first K offset served by a2
   __amdgpu_buffer_rsrc_t rs_x = rs_a;
-  auto seam = [&]() __attribute__((always_inline)) {
-    if (ik0 >= p.k1 && kbase == 0 && p.k1 < p.k) {
+  uint32_t xe[XI];
+  auto make_xe = [&](const int64_t ld) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < XI; ++j) xe[j] = xe2[j];
-      rs_x = rs_a2;
-      kbase = p.k1;
+    for (int j = 0; j < XI; ++j) {
+      const int r = block_m0 + (j * NW + wave) * 8 + lrow;
+      xe[j] = r < p.rows ? (uint32_t)r * (uint32_t)ld * 2u + lcb : DD_OOB;
     }
   };
-  seam();
+  auto seam = [&]() __attribute__((always_inline)) {
+    if (ik0 >= seam_k) {
+      make_xe(p.lda2);
+      rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a2), 0, p.a2_bytes, 0x00020000);
+      kbase = p.k1;
+      seam_k = 0x7fffffff;
+    }
+  };
+  make_xe(p.lda);
+  seam();                                          // a split-K slice that starts behind the seam
   auto issue_next = [&]() __attribute__((always_inline)) {
     T* xs = ring + islot * STAGE;
     T* ws = xs + BM * BK;
@@ -1305,78 +1322,152 @@ void dd_gemm3_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
   };
-  auto wait_stages = [&](const int ahead) __attribute__((always_inline)) {      // all but the `ahead` youngest stages landed
-    if (ahead <= 0) wait_vmcnt<0>();
-    else if (ahead == 1 || D <= 2) wait_vmcnt<(D > 1 ? 1 : 0) * LPS>();
-    else if (ahead == 2 || D <= 3) wait_vmcnt<(D > 2 ? 2 : 0) * LPS>();
-    else if (ahead == 3 || D <= 4) wait_vmcnt<(D > 3 ? 3 : 0) * LPS>();
-    else if (ahead == 4 || D <= 5) wait_vmcnt<(D > 4 ? 4 : 0) * LPS>();
-    else if (ahead == 5 || D <= 6) wait_vmcnt<(D > 5 ? 5 : 0) * LPS>();
-    else wait_vmcnt<(D > 6 ? 6 : 0) * LPS>();
+  // all but the `ahead` youngest stages (and the EXTRA operations issued behind them) have landed
+  auto wait_stages = [&](const int ahead, auto extra_c) __attribute__((always_inline)) {
+    constexpr int X = decltype(extra_c)::value;
+    if (ahead <= 0) wait_vmcnt<X>();
+    else if (ahead == 1 || D <= 2) wait_vmcnt<(D > 1 ? 1 : 0) * LPS + X>();
+    else if (ahead == 2 || D <= 3) wait_vmcnt<(D > 2 ? 2 : 0) * LPS + X>();
+    else if (ahead == 3 || D <= 4) wait_vmcnt<(D > 3 ? 3 : 0) * LPS + X>();
+    else if (ahead == 4 || D <= 5) wait_vmcnt<(D > 4 ? 4 : 0) * LPS + X>();
+    else if (ahead == 5 || D <= 6) wait_vmcnt<(D > 5 ? 5 : 0) * LPS + X>();
+    else wait_vmcnt<(D > 6 ? 6 : 0) * LPS + X>();
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
   constexpr int NMF = TN * TM, NRD = TN + TM;
 
   // stage 0 -> registers
-  wait_stages(min(D, nk) - 1);
+  wait_stages(min(D, nk) - 1, K0{});
   __builtin_amdgcn_s_barrier();
   read_half(K0{});
   read_half(K1{});
-  rslot = NSTAGE > 1 ? 1 : 0;
+  rslot = 1;
 
+  // One K-step in EXPLICIT issue order (the order is pinned with sched_barrier(0) after every unit: sched_group_barrier
+  // patterns were only loosely followed).  Early form: the DMAs one by one behind the first half's MFMAs, the ks=0
+  // reads behind the second half's, the ks=1 reads last.  STAG: the upper half of the waves issues its DMAs beside the
+  // SECOND half's MFMAs instead, so that the four waves of a workgroup (one per SIMD, in lock step behind the barrier)
+  // do not all queue at the CU's one address path at once.
+  const bool late = STAG && wave >= NW / 2;
+  auto steady = [&](auto late_c, auto issue_c) __attribute__((always_inline)) {
+    constexpr bool LATE = decltype(late_c)::value;
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    const T* wp0 = wbase + rslot * STAGE + cofs0;
+    const T* xp0 = xbase + rslot * STAGE + cofs0;
+    const T* wp1 = wbase + rslot * STAGE + cofs1;
+    const T* xp1 = xbase + rslot * STAGE + cofs1;
+    T* xs = ring + islot * STAGE;
+    T* ws = xs + BM * BK;
+    const uint32_t so_w = (uint32_t)ik0 * 2u, so_x = (uint32_t)(ik0 - kbase) * 2u;
+    auto dma = [&](const int u) __attribute__((always_inline)) {
+      if (u < WI) bdma16(rs_w, wv[u], so_w, ws + (u * NW + wave) * 8 * BK);
+      else bdma16(rs_x, xe[u - WI], so_x, xs + ((u - WI) * NW + wave) * 8 * BK);
+    };
+    auto rd = [&](const int ks, const int u) __attribute__((always_inline)) {
+      if (u < TN) wf[ks][u] = dd_as_v8<T>(dd_ld16((ks ? wp1 : wp0) + u * 16 * BK));
+      else xf[ks][u - TN] = dd_as_v8<T>(dd_ld16((ks ? xp1 : xp0) + (u - TN) * 16 * BK));
+    };
+    auto mf = [&](const int ks, const int u) __attribute__((always_inline)) {
+      const int i = u / TM, j = u % TM;
+      acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+    };
+    constexpr int NDM = ISSUE ? LPS : 0;
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!LATE) {
+#pragma unroll
+      for (int u = 0; u < (NMF > NDM ? NMF : NDM); ++u) {
+        if (u < NMF) mf(0, u);
+        if (u < NDM) dma(u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < (NMF > NRD ? NMF : NRD); ++u) {
+        if (u < NRD) rd(0, u);
+        if (u < NMF) mf(1, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NMF; ++u) mf(0, u);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < (NMF > NRD ? (NMF > NDM ? NMF : NDM) : (NRD > NDM ? NRD : NDM)); ++u) {
+        if (u < NRD) rd(0, u);
+        if (u < NDM) dma(u);
+        if (u < NMF) mf(1, u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NRD; ++u) rd(1, u);
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (ISSUE) {
+      ik0 += BK;
+      islot = islot + 1 == NSTAGE ? 0 : islot + 1;
+    }
+    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
+  };
   int c = 0;
-  for (; c + D < nk; ++c) {                        // steady state: stage c+1 certified, stage c+D issued
-    wait_vmcnt<(D - 2) * LPS>();
-    if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-    issue_next();
-    mfma_half(K0{});
-    read_half(K0{});
-    mfma_half(K1{});
-    read_half(K1{});
-    __builtin_amdgcn_s_setprio(0);
-    // schedule: the DMAs in the shadow of the first half's MFMAs, the ks=0 reads in the shadow of the second half's
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-    for (int i = 0; i < LPS; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      if (i + 1 < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    if (NMF - 1 - LPS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1 - LPS, 0);
-#pragma unroll
-    for (int i = 0; i < NRD; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (i < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    if (NMF - NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
-    seam();
+  auto main_loop = [&](auto late_c) __attribute__((always_inline)) {
+    for (; c + D < nk; ++c) {                      // steady state: stage c+1 certified, stage c+D issued
+      wait_vmcnt<(D - 2) * LPS>();
+      if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      steady(late_c, std::true_type{});
+      seam();
 #ifdef DD_DBG_STAMP
-    if (c == 0) DD_STAMP(3);
+      if (c == 0) DD_STAMP(3);
 #endif
+    }
+  };
+  if constexpr (STAG) {                            // two copies of the loop: a branch inside it would merge their schedules
+    if (late) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+  } else {
+    main_loop(std::false_type{});
   }
+
+  // ---- epilogue operands: issued behind the last DMA -------------------------------------------------------------
+  const int q4 = lane >> 4, c16 = lane & 15;
+  const int erow0 = block_m0 + wave_m * (TM * 16) + c16;
+  const int ecol0 = block_n0 + wave_n * (TN * 16) + q4 * (4 * TN);
+  const bool fast = FASTEPI && !p.partial && !p.hm_d && !p.out_f32 && !p.stat_out && !p.rowvec && (PRE_ACC || !p.accumulate) &&
+                    p.out_bytes != 0;
+  u32x4 pb[NG], pr[TM][NG], pa[PRE_ACC ? TM : 1][NG];
+  uint32_t off_o[TM][NG];
+  if constexpr (FASTEPI) {
+    const uint32_t e_bias = fast && p.bias ? (uint32_t)p.n * 2u : 0u;
+    const uint32_t e_res = fast && p.res ? p.res_bytes : 0u;
+    const uint32_t e_acc = fast && p.accumulate ? p.out_bytes : 0u;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bias), 0, e_bias, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, e_res, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, e_acc, 0x00020000);
+#pragma unroll
+    for (int g8 = 0; g8 < NG; ++g8) {
+      const int col = ecol0 + g8 * 8;
+      pb[g8] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, col < p.n ? (uint32_t)col * 2u : DD_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = erow0 + tm * 16;
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
+        const int col = ecol0 + g8 * 8;
+        const bool ok = row < p.rows && col < p.n;
+        off_o[tm][g8] = ok ? ((uint32_t)row * (uint32_t)p.ldc + (uint32_t)col) * 2u : DD_OOB;
+        pr[tm][g8] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? ((uint32_t)row * (uint32_t)p.ldres + (uint32_t)col) * 2u : DD_OOB, 0, 0);
+        if constexpr (PRE_ACC) pa[tm][g8] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, off_o[tm][g8], 0, 0);
+      }
+    }
+  }
+  using EX = std::integral_constant<int, EPI>;
+
   for (; c + 1 < nk; ++c) {                        // drain: nothing left to issue
-    wait_stages(min(nk - 2 - c, D - 2));
+    wait_stages(nk - 2 - c, EX{});
     if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-    mfma_half(K0{});
-    read_half(K0{});
-    mfma_half(K1{});
-    read_half(K1{});
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
-#pragma unroll
-    for (int i = 0; i < NRD; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (i < NMF) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    if (NMF - NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
+    steady(std::false_type{}, std::false_type{});
   }
   if (nk > 0) {                                    // last K-step: its fragments are in registers
     __builtin_amdgcn_s_setprio(1);
@@ -1385,9 +1476,43 @@ void dd_gemm3_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(0);
   }
   DD_STAMP(4);
-  if (p.tile_counters) __syncthreads();            // in-launch split-K: the flag word of store_tile aliases the ring
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile,
-                               reinterpret_cast<int*>(smem));
+  bool done = false;
+  if constexpr (FASTEPI) {
+    if (fast) {
+      const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+      const bool silu = p.act == DD_EPI_SILU;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8) {
+          float v[8], b[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+          dd_unpack8<T>(pb[g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (v[e] + b[e]) * p.alpha;
+          dd_unpack8<T>(pr[tm][g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+          if (silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = dd_silu_f(v[e]);
+          }
+          if constexpr (PRE_ACC) {
+            dd_unpack8<T>(pa[tm][g8], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
+        }
+      done = true;
+    }
+  }
+  if (!done) {
+    if (p.tile_counters) __syncthreads();          // in-launch split-K: the flag word of store_tile aliases the ring
+    store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile,
+                                 reinterpret_cast<int*>(smem));
+  }
 #ifdef DD_DBG_STAMP
   DD_STAMP(5);
   if (threadIdx.x == 0 && p.dbg_stamps) {
@@ -2156,6 +2281,8 @@ constexpr TileCfg kTiles[] = {
     {79, 2, 2, 4, 2, 104, "128x64/p4"},
     {80, 2, 2, 4, 4, 103, "128x128/p3"},
     {81, 4, 2, 4, 4, 103, "256x128/p3"},
+    {82, 2, 2, 3, 2, 103, "96x64/p3s"},             // ... with the upper wave half's DMAs in the second half of the step
+    {83, 2, 2, 1, 2, 104, "32x64/p4s"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -2417,12 +2544,12 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool GEGLU>
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool GEGLU, bool STAG = false>
 int launch_cfg3(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = dd_gemm3_kernel<T, WM, WN, TM, TN, NSTAGE, GEGLU>;
+  auto kern = dd_gemm3_kernel<T, WM, WN, TM, TN, NSTAGE, GEGLU, STAG>;
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   hipLaunchKernelGGL(kern, dim3(pl.tiles_m * pl.tiles_n, 1, pl.split), dim3(64 * WM * WN), smem, s, p);
@@ -2524,6 +2651,8 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 79: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 4, 2, 4, false>(p, pl, s); break;
     case 80: if constexpr (!CONV) return launch_cfg3<T, 2, 2, 4, 4, 3, GEGLU>(p, pl, s); break;
     case 81: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 4, 4, 3, GEGLU>(p, pl, s); break;
+    case 82: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false, true>(p, pl, s); break;
+    case 83: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false, true>(p, pl, s); break;
 #ifndef DD_DBG_ONLY_P
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
@@ -2769,6 +2898,13 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
       p.a_bytes = (uint32_t)((((int64_t)d->rows - 1) * d->lda + p.k1) * 2);
       p.a2_bytes = d->a2 ? (uint32_t)((((int64_t)d->rows - 1) * d->lda2 + (d->k - d->k1)) * 2) : 0u;
     }
+  }
+  {
+    // extents for the buffer-descriptor epilogue of the pipelined family (T output; 32-bit byte offsets)
+    const int64_t ob = (((int64_t)d->rows - 1) * d->ldc + d->n) * 2, rb = (((int64_t)d->rows - 1) * d->ldres + d->n) * 2;
+    const bool fits = ob < ((int64_t)1 << 31) && (!d->res || rb < ((int64_t)1 << 31));
+    p.out_bytes = fits ? (uint32_t)ob : 0u;
+    p.res_bytes = fits && d->res ? (uint32_t)rb : 0u;
   }
   p.persist = 0;
   p.partial = nullptr;

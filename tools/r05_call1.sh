@@ -7,7 +7,5 @@ timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "pipelined" > gpurun
 tail -5 gpurun_out/r05_c1_tests.log
 timeout 600 python tools/gemm3_ab.py 3 > gpurun_out/r05_gemm3_ab.txt 2>gpurun_out/r05_gemm3_ab.err
 cat gpurun_out/r05_gemm3_ab.txt
-DD_TIMELINE_TILES=0,72,73 timeout 600 bash tools/gemm2_timeline.sh > gpurun_out/r05_gemm3_timeline.txt 2>gpurun_out/r05_gemm3_timeline.err
+DD_TIMELINE_TILES=72,74,82 timeout 600 bash tools/gemm2_timeline.sh > gpurun_out/r05_gemm3_timeline.txt 2>gpurun_out/r05_gemm3_timeline.err
 cat gpurun_out/r05_gemm3_timeline.txt
-timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/r05_c1_bench.json 2>gpurun_out/r05_c1_bench.err
-tail -c 1500 gpurun_out/r05_c1_bench.json
