@@ -1162,7 +1162,7 @@ constexpr int gemm3_min_waves() {
   return WM * WN == 4 ? 2 : 1;
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool GEGLU, bool STAG = false>
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool GEGLU>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (gemm3_min_waves<WAVES_M, WAVES_N>()))
 void dd_gemm3_kernel(const GemmParams p) {
   using V8 = typename dd_vec<T>::v8;
@@ -1298,10 +1298,11 @@ void dd_gemm3_kernel(const GemmParams p) {
   const T* wbase = ring + BM * BK + (wave_n * TN * 16 + frow) * BK;
 
   DD_STAMP(1);
+  // prologue: stages 0 and 1 first; the remaining D-2 go out behind the first fragment reads (issuing all D up front
+  // kept the wave at the address path for 0.7 us before it even looked at stage 0)
 #pragma unroll
-  for (int s0 = 0; s0 < D; ++s0)
+  for (int s0 = 0; s0 < 2; ++s0)
     if (s0 < nk) { issue_next(); seam(); }
-  DD_STAMP(2);
 
   V8 wf[2][TN], xf[2][TM];
   int rslot = 0;                                   // ring slot of the stage whose fragments are read next
@@ -1338,20 +1339,22 @@ void dd_gemm3_kernel(const GemmParams p) {
   constexpr int NMF = TN * TM, NRD = TN + TM;
 
   // stage 0 -> registers
-  wait_stages(min(D, nk) - 1, K0{});
+  wait_stages(min(2, nk) - 1, K0{});
   __builtin_amdgcn_s_barrier();
   read_half(K0{});
   read_half(K1{});
   rslot = 1;
+#pragma unroll
+  for (int s0 = 2; s0 < D; ++s0)
+    if (s0 < nk) { issue_next(); seam(); }
+  DD_STAMP(2);
 
-  // One K-step in EXPLICIT issue order (the order is pinned with sched_barrier(0) after every unit: sched_group_barrier
-  // patterns were only loosely followed).  Early form: the DMAs one by one behind the first half's MFMAs, the ks=0
-  // reads behind the second half's, the ks=1 reads last.  STAG: the upper half of the waves issues its DMAs beside the
-  // SECOND half's MFMAs instead, so that the four waves of a workgroup (one per SIMD, in lock step behind the barrier)
-  // do not all queue at the CU's one address path at once.
-  const bool late = STAG && wave >= NW / 2;
-  auto steady = [&](auto late_c, auto issue_c) __attribute__((always_inline)) {
-    constexpr bool LATE = decltype(late_c)::value;
+  // One K-step in EXPLICIT issue order (pinned with sched_barrier(0) after every unit: sched_group_barrier patterns were
+  // only loosely followed): the DMAs one by one behind the first half's MFMAs, the ks=0 reads behind the second half's,
+  // the ks=1 reads last.  MEASURED AND REMOVED: a staggered form in which the upper half of the waves issued its DMAs
+  // beside the second half's MFMAs (so that the four waves do not queue at the CU's address path together) — 8.7 us
+  // either way on 1092x1280x1280, 0.25-0.26 us per K-step (profiles/r05_experiments.txt).
+  auto steady = [&](auto issue_c) __attribute__((always_inline)) {
     constexpr bool ISSUE = decltype(issue_c)::value;
     const T* wp0 = wbase + rslot * STAGE + cofs0;
     const T* xp0 = xbase + rslot * STAGE + cofs0;
@@ -1374,30 +1377,17 @@ void dd_gemm3_kernel(const GemmParams p) {
     };
     constexpr int NDM = ISSUE ? LPS : 0;
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (!LATE) {
 #pragma unroll
-      for (int u = 0; u < (NMF > NDM ? NMF : NDM); ++u) {
-        if (u < NMF) mf(0, u);
-        if (u < NDM) dma(u);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int u = 0; u < (NMF > NRD ? NMF : NRD); ++u) {
-        if (u < NRD) rd(0, u);
-        if (u < NMF) mf(1, u);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < NMF; ++u) mf(0, u);
+    for (int u = 0; u < (NMF > NDM ? NMF : NDM); ++u) {
+      if (u < NMF) mf(0, u);
+      if (u < NDM) dma(u);
       __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-      for (int u = 0; u < (NMF > NRD ? (NMF > NDM ? NMF : NDM) : (NRD > NDM ? NRD : NDM)); ++u) {
-        if (u < NRD) rd(0, u);
-        if (u < NDM) dma(u);
-        if (u < NMF) mf(1, u);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int u = 0; u < (NMF > NRD ? NMF : NRD); ++u) {
+      if (u < NRD) rd(0, u);
+      if (u < NMF) mf(1, u);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int u = 0; u < NRD; ++u) rd(1, u);
@@ -1409,23 +1399,15 @@ void dd_gemm3_kernel(const GemmParams p) {
     rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
   };
   int c = 0;
-  auto main_loop = [&](auto late_c) __attribute__((always_inline)) {
-    for (; c + D < nk; ++c) {                      // steady state: stage c+1 certified, stage c+D issued
-      wait_vmcnt<(D - 2) * LPS>();
-      if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      steady(late_c, std::true_type{});
-      seam();
+  for (; c + D < nk; ++c) {                        // steady state: stage c+1 certified, stage c+D issued
+    wait_vmcnt<(D - 2) * LPS>();
+    if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    steady(std::true_type{});
+    seam();
 #ifdef DD_DBG_STAMP
-      if (c == 0) DD_STAMP(3);
+    if (c == 0) DD_STAMP(3);
 #endif
-    }
-  };
-  if constexpr (STAG) {                            // two copies of the loop: a branch inside it would merge their schedules
-    if (late) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-  } else {
-    main_loop(std::false_type{});
   }
 
   // ---- epilogue operands: issued behind the last DMA -------------------------------------------------------------
@@ -1467,7 +1449,7 @@ void dd_gemm3_kernel(const GemmParams p) {
     wait_stages(nk - 2 - c, EX{});
     if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    steady(std::false_type{}, std::false_type{});
+    steady(std::false_type{});
   }
   if (nk > 0) {                                    // last K-step: its fragments are in registers
     __builtin_amdgcn_s_setprio(1);
@@ -2271,18 +2253,14 @@ constexpr TileCfg kTiles[] = {
     // wave: one wave per SIMD pair, 2 stages of 64 KB).  Candidates for the wide GEGLU projections and the big convs.
     {50, 2, 4, 8, 4, 2, "256x256/dma2"},
     // stages >= 100: pipelined LDS-DMA family (dd_gemm3_kernel, round 5; dense only), ring depth = stages - 100
-    {72, 2, 2, 3, 2, 103, "96x64/p3"},
-    {73, 2, 2, 3, 2, 104, "96x64/p4"},
-    {74, 2, 2, 3, 2, 105, "96x64/p5"},
+    {72, 2, 2, 3, 2, 103, "96x64/p3"},             // 60 KB: two workgroups per CU
+    {73, 2, 2, 3, 2, 105, "96x64/p5"},             // deeper rings: one workgroup per CU, cold weights 3-4 K-steps ahead
+    {74, 2, 2, 3, 2, 106, "96x64/p6"},
     {75, 4, 2, 3, 4, 103, "192x128/p3"},
     {76, 2, 2, 1, 2, 104, "32x64/p4"},
-    {77, 2, 2, 2, 4, 104, "64x128/p4"},
+    {77, 2, 2, 1, 2, 106, "32x64/p6"},
     {78, 2, 5, 5, 2, 103, "160x160/p3"},
-    {79, 2, 2, 4, 2, 104, "128x64/p4"},
-    {80, 2, 2, 4, 4, 103, "128x128/p3"},
-    {81, 4, 2, 4, 4, 103, "256x128/p3"},
-    {82, 2, 2, 3, 2, 103, "96x64/p3s"},             // ... with the upper wave half's DMAs in the second half of the step
-    {83, 2, 2, 1, 2, 104, "32x64/p4s"},
+    {79, 2, 2, 1, 2, 108, "32x64/p8"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -2544,12 +2522,12 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool GEGLU, bool STAG = false>
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool GEGLU>
 int launch_cfg3(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = dd_gemm3_kernel<T, WM, WN, TM, TN, NSTAGE, GEGLU, STAG>;
+  auto kern = dd_gemm3_kernel<T, WM, WN, TM, TN, NSTAGE, GEGLU>;
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   hipLaunchKernelGGL(kern, dim3(pl.tiles_m * pl.tiles_n, 1, pl.split), dim3(64 * WM * WN), smem, s, p);
@@ -2642,17 +2620,13 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 38: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 6, 3>(p, pl, s); break;
 #endif
     case 72: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false>(p, pl, s); break;
-    case 73: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 4, false>(p, pl, s); break;
-    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
+    case 73: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
+    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 6, false>(p, pl, s); break;
     case 75: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 3, 4, 3, GEGLU>(p, pl, s); break;
     case 76: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false>(p, pl, s); break;
-    case 77: if constexpr (!CONV) return launch_cfg3<T, 2, 2, 2, 4, 4, GEGLU>(p, pl, s); break;
+    case 77: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 6, false>(p, pl, s); break;
     case 78: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
-    case 79: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 4, 2, 4, false>(p, pl, s); break;
-    case 80: if constexpr (!CONV) return launch_cfg3<T, 2, 2, 4, 4, 3, GEGLU>(p, pl, s); break;
-    case 81: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 4, 4, 3, GEGLU>(p, pl, s); break;
-    case 82: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false, true>(p, pl, s); break;
-    case 83: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false, true>(p, pl, s); break;
+    case 79: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 8, false>(p, pl, s); break;
 #ifndef DD_DBG_ONLY_P
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);

@@ -19,18 +19,18 @@ def r(*s, scale=1.0):
 
 # (rows, n, k, kind, incumbent tile of the tracked table, challengers)
 SHAPES = [
-    (1092, 1280, 1280, "res", 52, (72, 74, 82, 76)),
-    (336, 1280, 1280, "res", 52, (72, 76, 83, 82)),
-    (4200, 640, 640, "res", 52, (72, 73, 82, 76)),
-    (4200, 640, 2560, "res", 52, (72, 74, 82, 79)),
-    (1092, 1280, 5120, "res", 52, (72, 74, 82, 76)),
-    (1092, 3840, 1280, "hm", 44, (75, 72, 82)),
-    (4200, 1920, 640, "hm", 44, (75, 72, 82)),
-    (16800, 320, 320, "res", 28, (78, 72, 82)),
+    (1092, 1280, 1280, "res", 52, (72, 73, 74)),
+    (336, 1280, 1280, "res", 52, (72, 76, 77, 79)),
+    (4200, 640, 640, "res", 52, (72, 73)),
+    (4200, 640, 2560, "res", 52, (72, 73)),
+    (1092, 1280, 5120, "res", 52, (72, 73, 74)),
+    (1092, 3840, 1280, "hm", 44, (75, 72, 73)),
+    (4200, 1920, 640, "hm", 44, (75, 72)),
+    (16800, 320, 320, "res", 28, (78, 72)),
     (16800, 960, 320, "hm", 28, (78, 75, 72)),
-    (1176, 640, 768, "plain", 52, (72, 76, 83, 82)),
-    (1092, 10240, 1280, "geglu", 44, (75, 81)),
-    (4200, 5120, 640, "geglu", 20, (81, 75)),
+    (1176, 640, 768, "plain", 52, (72, 76, 77)),
+    (12, 1280, 1280, "plain", 60, (76, 77, 79)),
+    (1092, 10240, 1280, "geglu", 44, (75,)),
 ]
 
 
