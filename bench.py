@@ -114,6 +114,72 @@ def synthetic_inputs(b, dtype, device, seed):
     return dev(lat), dev(prompt), dev(cam), [dev(boxes(NCAM)), dev(boxes(1))], [dev(c) for c in conds]
 
 
+def dropin_loop(unet, cns, inputs, ts, coefs, steps, g_scale=2.0, start=0, latents=None):
+    """The reference sampler's loop body written against the PUBLIC drop-in surfaces only
+    (pipeline/pipeline_bev_controlnet.py:381-504): CFG-double the latents (:384-386); every ControlNet's
+    `forward(sample[b, n, 4, h, w], timestep, camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond, ...,
+    return_dict=False)` and the sum of the 13 residuals over the branches with tensor ops (:405-431);
+    `unet(sample[(b n), 4, h, w], t, encoder_hidden_states=<tokens of branch 0>, down_block_additional_residuals=...,
+    mid_block_additional_residual=...).sample` (:476-484); guidance (:487-492) and the DDIM update (:497-499, eta = 0) in
+    torch.  What a maintainer who only swaps the classes by config override runs — nothing fused across the calls.
+    `ts` (device tensor) / `coefs` (host tensor): pipeline_bev_controlnet.ddim_schedule.  Returns the latents."""
+    lat, prompt, cam, boxes, conds = inputs
+    latents = lat.clone() if latents is None else latents
+    b, n = latents.shape[:2]
+    dtype = latents.dtype
+    for i in range(start, start + steps):
+        k = i % len(ts)
+        t = ts[k]
+        lmi = torch.cat([latents] * 2)                                   # uncond half first
+        down_sum = mid_sum = ctx0 = None
+        for j, cn in enumerate(cns):
+            down, mid, ctx = cn(lmi, t.expand(2 * b), cam, boxes[j], prompt, conds[j], conditioning_scale=1.0,
+                                guess_mode=False, return_dict=False, use_aug_text=False)
+            if j == 0:
+                down_sum, mid_sum, ctx0 = (list(down), mid, ctx) if len(cns) == 1 else ([d.clone() for d in down], mid.clone(), ctx)
+            else:
+                down_sum = [a + d for a, d in zip(down_sum, down)]
+                mid_sum = mid_sum + mid
+        eps = unet(lmi.reshape(2 * b * n, *lmi.shape[2:]), t, encoder_hidden_states=ctx0,
+                   down_block_additional_residuals=down_sum, mid_block_additional_residual=mid_sum).sample
+        eps = eps.reshape(2, b, n, *eps.shape[1:]).float()
+        eps = eps[0] + g_scale * (eps[1] - eps[0])
+        c = coefs[k]
+        x = latents.float()
+        x0 = (x - c[1] * eps) / c[0]
+        latents = (c[2] * x0 + c[3] * eps).to(dtype)
+    return latents
+
+
+def dropin_leg(args, dtype_name, device, fused_ms_per_step):
+    """`dropin`: steps/s of dropin_loop() — the path an unchanged `val_set_gen.py` / runner validation loop gets.  Each
+    forward() replays its own HIP graph (model_base.ForwardGraphs); the three graphs of a step run back to back on the
+    caller's stream, so the ControlNet || UNet-encoder overlap of the fused sampler is not available here."""
+    from dualdiff_amd.pipeline.pipeline_bev_controlnet import ddim_schedule
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    unet, cns = build_models(dtype, device)
+    inputs = synthetic_inputs(1, dtype, device, seed=1234)
+    ts, coefs = ddim_schedule(50)
+    ts = ts.to(device)
+    coefs = coefs.tolist()
+    with torch.no_grad():
+        lat = dropin_loop(unet, cns, inputs, ts, coefs, max(2, args.warmup))          # first call records the graphs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lat = dropin_loop(unet, cns, inputs, ts, coefs, args.steps, start=max(2, args.warmup), latents=inputs[0].clone())
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    ms = el / args.steps * 1e3
+    graphs = [len((m.__dict__.get("_fwd_graphs") or type("x", (), {"entries": {}})()).entries) for m in cns + [unet]]
+    out = {"value": args.steps / el, "unit": "steps/s", "ms_per_step": ms, "forward_graphs": graphs,
+           "vs_fused": round(fused_ms_per_step / ms, 3), "outputs_finite": bool(torch.isfinite(lat.float()).all().item()),
+           "loop": "reference-shaped loop through the public forward() surfaces (pipeline_bev_controlnet.py:381-504), torch "
+                   "residual sum + CFG + DDIM"}
+    del unet, cns
+    torch.cuda.empty_cache()
+    return out
+
+
 def _cpu_models():
     """fp32 CPU oracle models (kind 'port': restated diffusers blocks + reference-owned blocks, oracle/) with cheap
     seeded weights: matrices / conv kernels ~ N(0, 0.02^2) (SURVEY §8d's synthetic-weight rule; drawn once into a
@@ -395,9 +461,12 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
             sent, recv = sent + nblk * s_, recv + nblk * r_
         shard_msg = {"rank0_st_attn_sent_bytes_per_forward": sent, "rank0_temporal_gathered_bytes_per_forward": recv,
                      "exchanges_per_forward": 32, "frames_per_shard": plan.counts(), "cfg_halves_split": cfg_split}
-    den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=50,
+    sampler = getattr(args, "sampler", "ddim")
+    n_sample = 20 if sampler == "unipc" else 50            # steps of one sample: the reference's test pipeline runs UniPC-20
+    den = BEVDenoiser(unet, cns, guidance_scale=2.0, num_inference_steps=n_sample, sampler=sampler,
                       hoist_invariant=args.hoist_invariant, use_graph=graph,
                       parallel_branches=not args.serial_branches, **kw)
+    n_sample = den.num_inference_steps
     seed = 1234 + (rank // pairs if pairs <= 2 else 0)
     with torch.no_grad():
         # video (extension): the T frames of a scene are T more 6-view "scenes" of the batch, frame-major
@@ -423,9 +492,11 @@ def measure(args, dtype_name, device, dist, world, rank, backend, want_roofline)
         lat0 = den.lat2.clone()
 
         def run_step(k):
-            if k % 50 == 0 and k > 0:
+            if k % n_sample == 0 and k > 0:
                 den.lat2.copy_(lat0)
-            den.step(k % 50)
+                if den.hist is not None:
+                    den.hist.zero_()
+            den.step(k % n_sample)
 
         for i in range(args.warmup):
             run_step(i)
@@ -556,9 +627,15 @@ def compact_line(full, full_path=None, limit=LINE_LIMIT):
             out["cpu_baseline"]["bf16_value"] = b
     else:
         out["cpu_baseline"] = None
-    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling", "batched"):
+    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling", "batched", "unipc20", "dropin"):
         if full.get(k) is not None:
-            out[k] = full[k]
+            out[k] = dict(full[k]) if isinstance(full[k], dict) else full[k]
+    if isinstance(out.get("batched"), dict):
+        out["batched"].pop("roofline_classes", None)              # the full class table stays in the report file
+    for k in ("unipc20", "dropin"):
+        if isinstance(out.get(k), dict):
+            for kk in ("sampler", "loop"):
+                out[k].pop(kk, None)
     for k in ("view_split", "frame_split"):
         if k in cfg:
             out["config"][k] = {kk: vv for kk, vv in cfg[k].items() if kk != "note"}
@@ -568,7 +645,10 @@ def compact_line(full, full_path=None, limit=LINE_LIMIT):
                  lambda o: o.pop("tolerance", None),
                  lambda o: o["roofline"] and o["roofline"].pop("timing", None),
                  lambda o: o["cpu_baseline"] and o["cpu_baseline"].update(sample=o["cpu_baseline"]["sample"][:120]),
+                 lambda o: isinstance(o.get("batched"), dict) and o["batched"].get("roofline") and o["batched"]["roofline"].pop("next", None),
+                 lambda o: o.pop("unipc20", None),
                  lambda o: o.pop("batched", None),
+                 lambda o: o.pop("dropin", None),
                  lambda o: o.pop("strong_scaling", None),
                  lambda o: o["config"].pop("view_split", None) or o["config"].pop("frame_split", None),
                  lambda o: o["config"].update(workload=o["config"].get("workload", "")[:80])):
@@ -797,6 +877,9 @@ def main():
                     help="N = 1, default workload only: ALSO time this many scenes per GPU in one batch (headline dtype, no "
                          "roofline leg) and report it as `batched` — the serving-throughput form of the same step (value "
                          "stays the one-scene configuration SURVEY §8d names); 0 = off")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the `unipc20` (fused sampler with the reference test pipeline's UniPC-20 schedule) and `dropin` "
+                         "(reference-shaped loop through the public forward() surfaces) legs of the N = 1 line")
     ap.add_argument("--strong-leg", default="auto", choices=["auto", "off"],
                     help="N > 1 in the default scene-sharded mode: after the weak-scaling measurement rank 0 runs ONE scene "
                          "over all N GPUs (--parallelism view-split) as a fresh child job with a hard timeout and reports it "
@@ -858,13 +941,43 @@ def main():
             and not args.fp8_weights and not args.lora_rank and not args.no_graph):
         bargs = argparse.Namespace(**vars(args))
         bargs.scenes = args.batched_scenes
+        kt = os.environ.get("DD_BENCH_KERNEL_TABLE")
+        if kt:                                                         # the batched class table goes to its own file
+            os.environ["DD_BENCH_KERNEL_TABLE"] = kt.replace(".txt", "") + "_batched.txt"
         try:
-            br = measure(bargs, args.dtype, device, dist, world, rank, backend, False)
+            br = measure(bargs, args.dtype, device, dist, world, rank, backend, not args.no_roofline)
             batched = {"scenes_per_gpu": bargs.scenes, "value": args.steps * bargs.scenes / br["elapsed"],
                        "unit": "scene-steps/s", "ms_per_scene_step": br["elapsed"] / args.steps * 1e3 / bargs.scenes,
                        "outputs_finite": br["finite"]}
+            if br["roofline"]:                                     # dominant class of the 48-instance step (configs[2])
+                r = br["roofline"]
+                batched["roofline"] = {"kernel": _short_kernel(r["kernel"]), "bound": r["bound"], "achieved": r["achieved"],
+                                       "peak": r["peak"], "unit": r["unit"], "frac": r["frac"], "avg_us": r["avg_us"],
+                                       "launches_per_step": r["launches_per_step"],
+                                       "next": [{"k": _short_kernel(c["kernel"]), "n": c["launches_per_step"], "us": c["avg_us"],
+                                                 "b": c["bound"], "f": c["frac"]} for c in (r.get("classes") or [])[1:4]]}
+                batched["roofline_classes"] = r.get("classes")
         except Exception as e:                                     # informative leg: never fail the bench on it
             batched = {"scenes_per_gpu": bargs.scenes, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if kt:
+            os.environ["DD_BENCH_KERNEL_TABLE"] = kt
+    # the sampler the reference's test pipeline really runs (misc/test_utils.py:161-162: UniPC, 20 steps), fused form
+    unipc = dropin = None
+    if (world == 1 and args.parallelism == "scenes" and args.scenes == 1 and args.frames == 1 and not args.fp8_weights
+            and not args.lora_rank and not args.no_graph and not args.no_extra_legs):
+        uargs = argparse.Namespace(**vars(args))
+        uargs.sampler = "unipc"
+        try:
+            ur = measure(uargs, args.dtype, device, dist, world, rank, backend, False)
+            unipc = {"value": args.steps / ur["elapsed"], "unit": "steps/s", "ms_per_step": ur["elapsed"] / args.steps * 1e3,
+                     "ms_per_20_step_sample": ur["elapsed"] / args.steps * 1e3 * 20, "outputs_finite": ur["finite"],
+                     "sampler": "UniPC bh2 order 2, 20 steps, CFG 2 (misc/test_utils.py:161-162), one fused update kernel"}
+        except Exception as e:
+            unipc = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        try:
+            dropin = dropin_leg(args, args.dtype, device, res["elapsed"] / args.steps * 1e3)
+        except Exception as e:
+            dropin = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     want_strong = world > 1 and args.parallelism == "scenes" and args.strong_leg == "auto"
     if dist is not None:                       # the weak-scaling job is over: every rank leaves the group and frees its GPU memory
         torch.cuda.empty_cache()
@@ -942,6 +1055,10 @@ def main():
         out["strong_scaling"] = strong
     if batched is not None:
         out["batched"] = batched
+    if unipc is not None:
+        out["unipc20"] = unipc
+    if dropin is not None:
+        out["dropin"] = dropin
     path = _write_full_report(out, "%s_n%d_%s" % (args.dtype, world, args.parallelism))
     line = json.dumps(compact_line(out, path))
     assert len(line) < LINE_LIMIT, len(line)

@@ -18,10 +18,17 @@ from .. import ops as O
 
 
 # ----------------------------------------------------------------------------- helpers ----
+# Bumped whenever ANY module drops its packed weights (.to() / load_state_dict / device_init_, also on a sub-module
+# alone): HIP graphs captured behind the public forward() surfaces (model_base.ForwardGraphs) hold raw pointers to
+# the packed copies and are re-captured when the epoch they were recorded in is over.
+CACHE_EPOCH = [0]
+
+
 class _Cached(nn.Module):
     """Module with lazily packed kernel-layout weights; caches drop on .to()/load_state_dict."""
 
     def _drop_cache(self):
+        CACHE_EPOCH[0] += 1
         for k in [k for k in self.__dict__ if k.startswith("_pk_")]:
             del self.__dict__[k]
 
@@ -459,6 +466,7 @@ class Attention(_Cached):
         if isinstance(getattr(self, "processor", None), nn.Module) and not isinstance(processor, nn.Module):
             self._modules.pop("processor")
         self.processor = processor
+        CACHE_EPOCH[0] += 1          # forward graphs recorded with the old processor are over (model_base.ForwardGraphs)
 
     def prepare_attention_mask(self, attention_mask, target_length, batch_size=None, out_dim=3):
         if attention_mask is not None:

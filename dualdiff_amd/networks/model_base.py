@@ -10,7 +10,88 @@ import os
 import torch
 import torch.nn as nn
 
+import weakref
+
+from . import layers as _layers
 from .layers import HIPAttnProcessor, TimeEmbProjBank
+
+# HIP graphs behind the public forward() surfaces (round 5).  DD_GRAPH_FORWARD=0 switches them off process-wide,
+# `model.graph_forward = False` per model.
+GRAPH_FORWARD = os.environ.get("DD_GRAPH_FORWARD", "1") != "0"
+# data_ptr -> static output tensor of a live forward graph: a caller that hands such a tensor straight to the next
+# model (ControlNet residuals / tokens -> UNet, as pipeline_bev_controlnet.py:476-484 does with one branch) is read in
+# place instead of through a copy.  Weak: the entries die with the graph that owns the buffers.
+_STATIC_OUT = weakref.WeakValueDictionary()
+
+
+class ForwardGraphs:
+    """One HIP graph per (input shapes / dtypes / strides, scalar arguments, attribute flags) of a model's public
+    forward().  The reference's callers (`pipeline_bev_controlnet.py:405-446,476-484`, `val_set_gen.py`, the runner's
+    validation loop) call `controlnet(...)` / `unet(...)` through `forward()`; launched eagerly that is ~270 (ControlNet)
+    / ~290 (UNet) kernel launches from Python per call.  Here the first call with a new key runs once eagerly on the
+    capture stream (tile tuning, weight packing, workspace sizing), records the same code into a graph on STATIC input
+    buffers, and every later call copies its inputs into those buffers (skipped when the caller hands in the static
+    output of another forward graph) and replays.  Outputs are views of graph-owned buffers: valid until the next call
+    of the same model with the same key — what the sampler loop needs (residuals and tokens are consumed within the
+    step); `forward()` clones the 4-channel noise prediction.
+    Invalidation: `load_state_dict` / `.to()` / `set_attn_processor` on the model (`_invalidate`), any packed-weight
+    drop anywhere below it (layers.CACHE_EPOCH), and attribute pokes such as `use_txt_con_fusion` (the flag snapshot
+    is part of the key, misc/test_utils.py:123-136).  Weights rewritten through `.data` must be followed by
+    `model._invalidate()`, as for the packed-weight caches."""
+
+    def __init__(self):
+        self.entries = {}
+        self.no_alias = set()
+
+    def clear(self):
+        self.entries.clear()
+
+    @staticmethod
+    def flags(module):
+        return tuple(sorted((k, v) for k, v in vars(module).items()
+                            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str, type(None)))))
+
+    def call(self, key, tensors, impl):
+        """tensors: flat list of tensors / None; impl(list) -> flat list of output tensors."""
+        key = (key, tuple(None if t is None else (tuple(t.shape), t.dtype, tuple(t.stride())) for t in tensors))
+        e = self.entries.get(key)
+        if e is not None and e["epoch"] != _layers.CACHE_EPOCH[0]:
+            e = None
+        if e is not None:
+            for i, (st, t) in enumerate(zip(e["static"], tensors)):
+                if t is None or st.data_ptr() == t.data_ptr():
+                    continue
+                if e["alias"][i]:                 # the caller no longer passes that graph's output: own the buffer
+                    self.no_alias.add(key)
+                    e = None
+                    break
+                st.copy_(t, non_blocking=True)
+        if e is None:
+            e = self._capture(key, tensors, impl)
+            self.entries[key] = e
+        e["graph"].replay()
+        return e["out"]
+
+    def _capture(self, key, tensors, impl):
+        static, alias = [], []
+        for t in tensors:
+            own = t is None or key in self.no_alias or _STATIC_OUT.get(t.data_ptr()) is None
+            alias.append(not own)
+            static.append(None if t is None else (t.clone(memory_format=torch.preserve_format) if own else t))
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            impl(static)                          # eager on the capture stream: tuning, packing, workspaces of this stream
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out = impl(static)
+        cur.wait_stream(s)
+        for o in out:
+            if torch.is_tensor(o):
+                _STATIC_OUT[o.data_ptr()] = o
+        return {"graph": g, "static": static, "alias": alias, "out": out, "epoch": _layers.CACHE_EPOCH[0]}
 
 
 class Config(dict):
@@ -58,6 +139,31 @@ class ModelBase(nn.Module):
     def _invalidate(self):
         if self.__dict__.get("_temb_bank") is not None:
             self.__dict__["_temb_bank"].invalidate()
+        if self.__dict__.get("_fwd_graphs") is not None:
+            self.__dict__["_fwd_graphs"].clear()
+
+    # -- HIP graphs behind forward() -----------------------------------------------------------
+    graph_forward = True
+
+    def _graphs(self):
+        """The forward-graph cache, or None when this call must run eagerly: switched off, already inside a capture
+        (BEVDenoiser records the whole step itself), a sharded model (its exchanges cannot live in a private graph), or
+        a foreign attention processor (an arbitrary callable may do anything, e.g. read host state)."""
+        if not (GRAPH_FORWARD and self.graph_forward) or torch.cuda.is_current_stream_capturing():
+            return None
+        if getattr(self, "view_shard", None) is not None or getattr(self, "frame_shard", None) is not None:
+            return None
+        ok = self.__dict__.get("_fwd_builtin_procs")
+        if ok is None or ok[1] != _layers.CACHE_EPOCH[0]:    # Attention.set_processor bumps the epoch
+            from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor
+            builtin = (HIPAttnProcessor, Adapter_XFormersAttnProcessor, XFormersAttnProcessor)
+            ok = (all(type(p) in builtin for p in self.attn_processors.values()), _layers.CACHE_EPOCH[0])
+            self.__dict__["_fwd_builtin_procs"] = ok
+        if not ok[0]:
+            return None
+        if self.__dict__.get("_fwd_graphs") is None:
+            self.__dict__["_fwd_graphs"] = ForwardGraphs()
+        return self.__dict__["_fwd_graphs"]
 
     def _apply(self, fn, *a, **k):
         self._invalidate()
@@ -81,6 +187,8 @@ class ModelBase(nn.Module):
                 f"match the number of attention layers: {count}.")
         for name, m in [(n, mm) for n, mm in self.named_modules() if hasattr(mm, "set_processor")]:
             m.set_processor(processor.pop(name + ".processor") if isinstance(processor, dict) else processor)
+        self.__dict__["_fwd_builtin_procs"] = None
+        self._invalidate()
 
     def set_default_attn_processor(self):
         self.set_attn_processor(HIPAttnProcessor())

@@ -223,27 +223,38 @@ class UNet2DConditionModelMultiview(ModelBase):
             raise NotImplementedError("cross_attention_kwargs is unused by the DualDiff pipeline")
         if not sample.is_cuda:
             raise RuntimeError("dualdiff_amd runs on the GPU only; got a %s tensor" % sample.device)
-        dt = self.dtype
         m = sample.shape[0]
+        n_down = None if down_block_additional_residuals is None else len(down_block_additional_residuals)
+        tensors = [sample, self._timesteps(timestep, m, sample.device), encoder_hidden_states]
+        tensors += list(down_block_additional_residuals or ()) + [mid_block_additional_residual]
+        graphs = self._graphs()
+        if graphs is None:
+            out = self._forward_flat(tensors, n_down)[0]
+        else:
+            # the noise prediction is small (4 channels): hand the caller its own copy, not a view of graph memory
+            out = graphs.call(("unet", n_down, graphs.flags(self)), tensors, lambda ts: self._forward_flat(ts, n_down))[0].clone()
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    def _forward_flat(self, tensors, n_down):
+        """forward() on a flat tensor list [sample, t (m,) fp32, encoder_hidden_states, *down residuals, mid residual]
+        (what ForwardGraphs records): NCHW in, NCHW out, residuals NCHW-shaped (channels_last strides are zero-copy)."""
+        sample, t_f32, encoder_hidden_states = tensors[:3]
+        down = None if n_down is None else tensors[3:3 + n_down]
+        mid = tensors[-1]
+        dt = self.dtype
         x, m, h, w = to_nhwc(sample.to(dt))
         if x.shape[1] != self.conv_in.cin_pad:
             x = torch.nn.functional.pad(x, (0, self.conv_in.cin_pad - x.shape[1]))
-        down_res = None
-        if down_block_additional_residuals is not None:
-            down_res = [to_nhwc(r.to(dt))[0] for r in down_block_additional_residuals]
-        mid_res = None
-        if mid_block_additional_residual is not None:
-            mid_res = to_nhwc(mid_block_additional_residual.to(dt))[0]
+        down_res = None if down is None else [to_nhwc(r.to(dt))[0] for r in down]
+        mid_res = None if mid is None else to_nhwc(mid.to(dt))[0]
         ctx = encoder_hidden_states.to(dt)
         lc = ctx.shape[1]
         ctx2d = ctx.reshape(m * lc, ctx.shape[2])
         if not ctx2d.is_contiguous():
             ctx2d = ctx2d.contiguous()
-        out = self.forward_nhwc(x, m, h, w, self._timesteps(timestep, m, sample.device), ctx2d, lc,
-                                down_res, mid_res)
-        if not return_dict:
-            return (out,)
-        return UNet2DConditionOutput(sample=out)
+        return [self.forward_nhwc(x, m, h, w, t_f32, ctx2d, lc, down_res, mid_res)]
 
     def forward_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, down_res=None, mid_res=None):
         """x: (m*h*w, 8) NHWC latents (4 channels zero-padded to 8); residuals: NHWC 2-D tensors in

@@ -427,6 +427,35 @@ class BEVControlNetModel(ModelBase):
                                   * conditioning_scale).tolist()
         if not sample.is_cuda:
             raise RuntimeError("dualdiff_amd runs on the GPU only; got a %s tensor" % sample.device)
+        b, n_cam = sample.shape[:2]
+        m = b * n_cam
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)], device=sample.device)
+        t = t.to(device=sample.device, dtype=torch.float32).reshape(-1)
+        t = t.repeat_interleave(m // t.numel()) if t.numel() != m else t          # :951-952
+        box_keys = None if bboxes_3d_data is None else tuple(sorted(bboxes_3d_data))
+        tensors = [sample, t.contiguous(), camera_param, encoder_hidden_states, controlnet_cond]
+        tensors += [] if box_keys is None else [bboxes_3d_data[k] for k in box_keys]
+        scale = tuple(conditioning_scale) if isinstance(conditioning_scale, (list, tuple)) else float(conditioning_scale)
+        graphs = self._graphs()
+        if graphs is None:
+            outs = self._forward_flat(tensors, box_keys, scale, use_aug_text)
+        else:
+            outs = graphs.call(("controlnet", box_keys, scale, bool(use_aug_text), graphs.flags(self)), tensors,
+                               lambda ts: self._forward_flat(ts, box_keys, scale, use_aug_text))
+        down, mid, ctx = list(outs[:-2]), outs[-2], outs[-1]
+        if not return_dict:
+            return down, mid, ctx
+        return BEVControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid,
+                                   encoder_hidden_states_with_cam=ctx)
+
+    def _forward_flat(self, tensors, box_keys, conditioning_scale, use_aug_text):
+        """forward() on a flat tensor list [sample (b, n, 4, h, w), t (b*n,) fp32, camera_param, encoder_hidden_states,
+        controlnet_cond, *bboxes_3d_data values in key order] (what ForwardGraphs records).  Returns the 12 down
+        residuals + the mid residual as logical-NCHW views of the NHWC buffers, then the tokens with the camera token."""
+        sample, t, camera_param, encoder_hidden_states, controlnet_cond = tensors[:5]
+        bboxes_3d_data = None if box_keys is None else dict(zip(box_keys, tensors[5:]))
         dt = self.dtype
         b, n_cam = sample.shape[:2]
         prep = self.prepare_condition(camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
@@ -434,20 +463,9 @@ class BEVControlNetModel(ModelBase):
         x, m, h, w = to_nhwc(sample.reshape(b * n_cam, *sample.shape[2:]).to(dt))
         if x.shape[1] != self.conv_in.cin_pad:
             x = torch.nn.functional.pad(x, (0, self.conv_in.cin_pad - x.shape[1]))
-        t = timestep
-        if not torch.is_tensor(t):
-            t = torch.tensor([float(t)], device=sample.device)
-        t = t.to(device=sample.device, dtype=torch.float32).reshape(-1)
-        t = t.repeat_interleave(m // t.numel()) if t.numel() != m else t          # :951-952
-        outs = self.forward_nhwc(x, m, h, w, t.contiguous(), prep, conditioning_scale)
-        down = [as_nchw_view(o, m, oh, ow) for o, oh, ow in outs[:-1]]
-        mo, mh, mw = outs[-1]
-        mid = as_nchw_view(mo, m, mh, mw)
-        ctx = prep["ctx"]
-        if not return_dict:
-            return down, mid, ctx
-        return BEVControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid,
-                                   encoder_hidden_states_with_cam=ctx)
+        scale = list(conditioning_scale) if isinstance(conditioning_scale, tuple) else conditioning_scale
+        outs = self.forward_nhwc(x, m, h, w, t, prep, scale)
+        return [as_nchw_view(o, m, oh, ow) for o, oh, ow in outs] + [prep["ctx"]]
 
 
 # token preparation as four launches (csrc/tokens.hip) instead of ~20 tensor ops per branch; False = the tensor-op chain

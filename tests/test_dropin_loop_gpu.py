@@ -25,30 +25,9 @@ def test_reference_shaped_loop_equals_fused_sampler(gpu, dtype):
     g_scale, steps = 2.0, 2
     ts, coefs = ddim_schedule(50)
     with torch.no_grad():
-        # ---- the reference-shaped loop through forward() only ------------------------------------------------------
-        latents = lat.clone()                                               # (b, n, 4, h, w)
-        b, n = latents.shape[:2]
-        for i in range(steps):
-            t = ts[i].to(dev)
-            lmi = torch.cat([latents] * 2)                                   # :384-386, uncond half first
-            down_sum = mid_sum = ctx0 = None
-            for j, cn in enumerate(cns):                                     # :405-431
-                down, mid, ctx = cn(lmi, t.expand(2 * b), cam, boxes[j], prompt, conds[j], conditioning_scale=1.0,
-                                    guess_mode=False, return_dict=False, use_aug_text=False)
-                if j == 0:
-                    down_sum, mid_sum, ctx0 = [d.clone() for d in down], mid.clone(), ctx
-                else:
-                    down_sum = [a + d for a, d in zip(down_sum, down)]
-                    mid_sum = mid_sum + mid
-            eps = unet(lmi.reshape(2 * b * n, *lmi.shape[2:]), t, encoder_hidden_states=ctx0,
-                       down_block_additional_residuals=down_sum, mid_block_additional_residual=mid_sum).sample   # :476-484
-            eps = eps.reshape(2, b, n, *eps.shape[1:]).float()
-            eps = eps[0] + g_scale * (eps[1] - eps[0])                       # :487-492
-            c = coefs[i]
-            x = latents.float()
-            x0 = (x - c[1] * eps) / c[0]                                     # DDIM, eta = 0 (:497-499 with DDIMScheduler)
-            latents = (c[2] * x0 + c[3] * eps).to(dtype)
-        loop_latents = latents
+        # ---- the reference-shaped loop through forward() only (bench.dropin_loop: the `dropin` leg times the same code) ----
+        loop_latents = bench.dropin_loop(unet, cns, (lat, prompt, cam, boxes, conds), ts.to(dev), coefs.tolist(), steps,
+                                         g_scale=g_scale)
         # ---- the fused sampler -------------------------------------------------------------------------------------
         den = BEVDenoiser(unet, cns, guidance_scale=g_scale, num_inference_steps=50, use_graph=True)
         den.set_inputs(lat, prompt, cam, boxes, conds)

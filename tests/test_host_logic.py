@@ -311,7 +311,18 @@ def _synthetic_full_report(n_classes=40):
             "other_dtype": {"dtype": "bf16", "value": 89.18, "unit": "steps/s", "ms_per_step": 11.21, "outputs_finite": True},
             "speedup_vs_cpu": 1161.5,
             "strong_scaling": {"mode": "view-split", "value": 123.4, "ms_per_step": 8.1, "speedup_vs_n1_ms": 1.4,
-                               "message_bytes": 7950000, "verified_on_multi_gpu_hardware": True, "graph": "piecewise"}}
+                               "message_bytes": 7950000, "verified_on_multi_gpu_hardware": True, "graph": "piecewise"},
+            # round 5 legs
+            "batched": {"scenes_per_gpu": 4, "value": 116.08, "unit": "scene-steps/s", "ms_per_scene_step": 8.61,
+                        "outputs_finite": True,
+                        "roofline": {"kernel": "dd_conv3s<f16,4,2,6,2,5,1,0>", "bound": "mfma", "achieved": 901.2, "peak": 2500.0,
+                                     "unit": "TFLOP/s", "frac": 0.3605, "avg_us": 151.2, "launches_per_step": 33,
+                                     "next": [{"k": "dd_attn5<f16,D40>", "n": 14, "us": 240.1, "b": "mfma", "f": 0.27}] * 3},
+                        "roofline_classes": rows},
+            "unipc20": {"value": 88.1, "unit": "steps/s", "ms_per_step": 11.35, "ms_per_20_step_sample": 227.0,
+                        "outputs_finite": True, "sampler": "u" * 120},
+            "dropin": {"value": 77.2, "unit": "steps/s", "ms_per_step": 12.95, "forward_graphs": [1, 1, 1], "vs_fused": 0.87,
+                       "outputs_finite": True, "loop": "l" * 200}}
 
 
 def test_bench_line_stays_parseable_and_short():
@@ -335,6 +346,10 @@ def test_bench_line_stays_parseable_and_short():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c)
     assert "1e-3" in back["tolerance"] and back["full_report"].endswith(".json")
     assert back["strong_scaling"]["mode"] == "view-split"
+    # round 5: the three new legs ride in the same line, without their free-text and without the batched class table
+    assert back["dropin"]["vs_fused"] == 0.87 and "loop" not in back["dropin"]
+    assert back["unipc20"]["ms_per_20_step_sample"] == 227.0 and "sampler" not in back["unipc20"]
+    assert back["batched"]["roofline"]["frac"] == 0.3605 and "roofline_classes" not in back["batched"]
     # degenerate inputs: no roofline / no CPU leg (N > 1 ranks), and an absurdly long free-text field still fits
     bare = dict(full, roofline=None, cpu_baseline=None)
     assert len(json.dumps(bench.compact_line(bare))) < 4096
