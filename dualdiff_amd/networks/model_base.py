@@ -58,6 +58,7 @@ class ForwardGraphs:
         if e is not None and e["epoch"] != _layers.CACHE_EPOCH[0]:
             e = None
         if e is not None:
+            dst, src = [], []
             for i, (st, t) in enumerate(zip(e["static"], tensors)):
                 if t is None or st.data_ptr() == t.data_ptr():
                     continue
@@ -65,7 +66,10 @@ class ForwardGraphs:
                     self.no_alias.add(key)
                     e = None
                     break
-                st.copy_(t, non_blocking=True)
+                dst.append(st)
+                src.append(t)
+            if e is not None and dst:             # one multi-tensor launch per dtype group instead of one copy per input
+                torch._foreach_copy_(dst, src, non_blocking=True)
         if e is None:
             e = self._capture(key, tensors, impl)
             self.entries[key] = e
