@@ -65,8 +65,8 @@ def build_models(dtype, device, dual=True, frames=1, fp8=False, lora_rank=0):
         g = torch.Generator(device=device).manual_seed(77)
         lora = {k: torch.randn(shape, generator=g, device=device) * 0.02 for k, shape in sorted(lora_keys(unet, lora_rank).items())}
         fold_lora_(unet, lora, 1.0)
-    if fp8:                   # EXTENSION (configs[4]): W8A8 on the fp8 matrix path (fp8 == "weights": the round-2 weights-only form)
-        enable_fp8_weights(unet, mfma=fp8 != "weights")
+    if fp8:                   # EXTENSION (configs[4]): W8A8 on the fp8 matrix path
+        enable_fp8_weights(unet)
     cns = []
     for i, occ3d in enumerate((False, True) if dual else (False,)):
         with torch.device(device):
@@ -82,7 +82,7 @@ def build_models(dtype, device, dual=True, frames=1, fp8=False, lora_rank=0):
         if occ3d:
             cn.controlnet_cond_embedding = None
         if fp8:
-            enable_fp8_weights(cn, mfma=fp8 != "weights")
+            enable_fp8_weights(cn)
         cns.append(cn.eval())
     return unet.eval(), cns
 
@@ -841,10 +841,9 @@ def main():
                     help="EXTENSION (BASELINE configs[3], no reference semantics): frames per scene; > 1 runs the video "
                          "UNet (ST-Attn + temporal attention, dualdiff_amd/networks/video_blocks.py) on 2 x 6 x T "
                          "view-instances per scene; a step then advances all T frames")
-    ap.add_argument("--fp8-weights", nargs="?", const="mfma", default=None, choices=["mfma", "weights"],
-                    help="EXTENSION (configs[4]): 'mfma' (default when the flag is given): W8A8 — e4m3fn weights AND activations on "
-                         "the CDNA4 fp8 matrix instruction for the fused Q|K|V and GEGLU projections at the 640 / 1280-channel "
-                         "levels; 'weights': the round-2 form (e4m3fn weights dequantised in registers, 16-bit MFMA)")
+    ap.add_argument("--fp8-weights", nargs="?", const="mfma", default=None, choices=["mfma"],
+                    help="EXTENSION (configs[4]): W8A8 — e4m3fn weights AND activations on the CDNA4 fp8 matrix instruction for "
+                         "the fused Q|K|V and GEGLU projections at the 640 / 1280-channel levels")
     ap.add_argument("--lora-rank", type=int, default=0,
                     help="EXTENSION (configs[4]): fold a synthetic rank-r attention LoRA into the UNet before running")
     ap.add_argument("--hoist-invariant", action="store_true")

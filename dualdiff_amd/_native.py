@@ -33,11 +33,8 @@ class GemmDesc(Structure):
         ("ws", c_void_p), ("ws_bytes", c_int64),
         ("ln_colsum", c_void_p), ("ln_bias", c_void_p), ("ln_eps", c_float), ("out_f32", c_int32), ("ln_stats_out", c_void_p), ("ln_stats_in", c_void_p),
         ("out_headmajor_d", c_int32), ("hm_scaled_planes", c_int32), ("hm_scale", c_float),
-        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("w_scale", c_void_p),
         ("phase", c_int32),
         ("ln_out", c_void_p), ("ld_ln_out", c_int64), ("lno_gamma", c_void_p), ("lno_beta", c_void_p),
-        ("splitk_inkernel", c_int32),
-        ("prefetch", c_void_p), ("prefetch_bytes", c_int64),
     ]
 
 
@@ -65,7 +62,7 @@ class BoxTokensDesc(Structure):
         ("rows", c_int32), ("points_per_box", c_int32), ("num_freqs", c_int32), ("include_input", c_int32),
         ("class_token_dim", c_int32), ("cls_offset", c_int32),
         ("ld_cat", c_int64),
-        ("normalize", c_int32), ("points_dtype", c_int32), ("dtype", c_int32), ("reserved", c_int32),
+        ("normalize", c_int32), ("points_dtype", c_int32), ("dtype", c_int32), ("n_classes", c_int32),
         ("freqs", c_float * 16), ("xyz_min", c_float * 3), ("xyz_range", c_float * 3),
     ]
 
@@ -110,8 +107,6 @@ SIGNATURES = {
                                     c_void_p, c_int64, c_void_p]),
     "dd_groupnorm_workspace_bytes": (c_int64, [c_int32, c_int32]),
     "dd_groupnorm_is_fused": (c_int32, [c_int32, c_int32, c_int32]),
-    "dd_groupnorm_is_coop": (c_int32, [c_int32, c_int32, c_int32]),
-    "dd_groupnorm_set_coop": (None, [c_int32]),
     "dd_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                c_int32, c_void_p]),
     "dd_attention": (c_int32, [POINTER(AttnDesc), c_void_p]),
@@ -153,7 +148,7 @@ SIGNATURES = {
                                    c_int64, c_int32, c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _LIB = None
 
 

@@ -12,7 +12,7 @@
 //    xor-shuffles (lane groups 16/32 apart hold the other keys of the same query row).
 //  * head_dim is padded with zeros in LDS to a multiple of 32 for QK^T (40->64, 80->96) and
 //    to a multiple of 16 for PV (40->48); rows are padded by 16 B against bank conflicts.
-//  * register-staged prefetch of the next K/V tile while the current one is consumed.
+//  * K/V tiles staged by buffer loads with the hardware range check (see the kernel's comment).
 //  * kv_batch_map + accumulate implement the neighbour-view attention (attn4) as two calls
 //    that read the neighbours' K/V in place and sum the normalised outputs.
 #include "dd_common.h"
@@ -49,263 +49,9 @@ struct AttnParams {
 };
 
 
-template <typename T, int D, int QT, bool TR, int KV_TILE>
-__global__ __launch_bounds__(256)
-void dd_attn_kernel(const AttnParams p) {
-  using V8 = typename dd_vec<T>::v8;
-  using V4 = typename dd_vec<T>::v4;
-  constexpr int DQ = (D + 31) / 32 * 32;       // padded head dim for QK^T
-  constexpr int KSTEPS = DQ / 32;
-  constexpr int DVT = (D + 15) / 16;           // 16-wide d tiles for PV
-  // LDS row strides (elements).  Pads chosen by enumerating the bank pattern of the ds_read_b128
-  // lane groups (K) and of the ds_read_b64_tr_b16 halves (V): +32 B per K row is conflict-free for
-  // all three head dims; V rows need no pad at d = 40 / 80 and +32 B at d = 160.
-  constexpr int KSTR = DQ + 16;
-  constexpr int VSTR = DVT * 16 + (D == 160 ? 16 : 0);
-  constexpr int KCH = DQ / 8;                  // 16-B chunks per K row in LDS
-  constexpr int VCH = DVT * 2;                 // 16-B chunks per V row in LDS
-  constexpr int DCH = D / 8;                   // valid chunks per global row
-  // When the PV tile has spare columns (d = 40 -> 48) column D of the V tile holds 1.0, so the MFMA
-  // accumulates the softmax denominator (sum of the *rounded* probabilities, consistent with the
-  // numerator) for free and the VALU row-sum disappears.
-  constexpr bool ONES = (D % 16) != 0;
-  constexpr int K_PER_THR = (KV_TILE * KCH + 255) / 256;
-  constexpr int V_PER_THR = (KV_TILE * VCH + 255) / 256;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* Ks = reinterpret_cast<T*>(smem);
-  T* Vs = Ks + KV_TILE * KSTR;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int g = lane >> 4;        // lane group 0..3
-  const int c = lane & 15;
-
-  // XCD-aware order: workgroups i, i+8, ... share an XCD (and its L2); give each XCD a contiguous
-  // run of (batch*head, q-block) items so all q-blocks of a head read that head's K/V through ONE L2
-  // (a plain 2-D grid spreads them over the 8 XCDs: K/V were fetched 8x, rocprofv3 FETCH_SIZE).
-  const int nqb = p.nqb;
-  const int nwg = nqb * p.batch * p.heads;
-  const int xcd = blockIdx.x & 7;
-  const int xq = nwg >> 3, xr = nwg & 7;
-  const int item = ((xcd < xr) ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  const int bh = item / nqb;
-  const int qb = item - bh * nqb;
-  const int b = bh / p.heads;
-  const int h = bh - b * p.heads;
-  const int kb = p.kv_map ? p.kv_map[b] : b;
-  const int q0 = (qb * 4 + wave) * (QT * 16);
-
-  const T* qbase = reinterpret_cast<const T*>(p.q) + (int64_t)b * p.qbs + h * p.qhs;
-  const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * p.khs;
-  const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * p.vhs;
-
-  // ---- Q fragments (B operand of S^T = K Q^T), kept in registers -----------------------
-  V8 qf[QT][KSTEPS];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int qrow = q0 + qt * 16 + c;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int d0 = ks * 32 + g * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (qrow < p.lq && d0 < D) v = dd_ld16(qbase + (int64_t)qrow * p.ldq + d0);
-      qf[qt][ks] = dd_as_v8<T>(v);
-    }
-  }
-
-  f32x4 oacc[DVT][QT];
-#pragma unroll
-  for (int i = 0; i < DVT; ++i)
-#pragma unroll
-    for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[QT], l_run[QT];
-#pragma unroll
-  for (int j = 0; j < QT; ++j) { m_run[j] = -1e30f; l_run[j] = 0.f; }
-
-  u32x4 kreg[K_PER_THR], vreg[V_PER_THR];
-  const T one_t = (T)1.0f;
-  unsigned short one_u16;
-  __builtin_memcpy(&one_u16, &one_t, 2);
-  const unsigned one_bits = one_u16;            // element 0 of the 16-B chunk = 1.0, rest 0
-
-  auto load_kv = [&](int tile0) {
-#pragma unroll
-    for (int i = 0; i < K_PER_THR; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / KCH, ch = idx - row * KCH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < KV_TILE * KCH && ch < DCH && tile0 + row < p.lk)
-        v = dd_ld16(kbase + (int64_t)(tile0 + row) * p.ldk + ch * 8);
-      kreg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < V_PER_THR; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / VCH, ch = idx - row * VCH;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < KV_TILE * VCH && ch < DCH && tile0 + row < p.lk)
-        v = dd_ld16(vbase + (int64_t)(tile0 + row) * p.ldv + ch * 8);
-      if (ONES && idx < KV_TILE * VCH && ch == DCH) v[0] = one_bits;
-      vreg[i] = v;
-    }
-  };
-  auto store_kv = [&]() {
-#pragma unroll
-    for (int i = 0; i < K_PER_THR; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / KCH, ch = idx - row * KCH;
-      if (idx < KV_TILE * KCH) dd_st16(Ks + row * KSTR + ch * 8, kreg[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < V_PER_THR; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / VCH, ch = idx - row * VCH;
-      if (idx < KV_TILE * VCH) dd_st16(Vs + row * VSTR + ch * 8, vreg[i]);
-    }
-  };
-
-  const int ntiles = (p.lk + KV_TILE - 1) / KV_TILE;
-  load_kv(0);
-
-  for (int it = 0; it < ntiles; ++it) {
-    const int tile0 = it * KV_TILE;
-    __syncthreads();            // previous tile fully consumed by every wave
-    store_kv();
-    __syncthreads();            // tile visible
-    if (it + 1 < ntiles) load_kv(tile0 + KV_TILE);   // prefetch under the MFMAs below
-
-#pragma unroll
-    for (int cc = 0; cc < KV_TILE / 32; ++cc) {
-      const int key0 = tile0 + cc * 32;
-      if (key0 >= p.lk) break;                        // uniform
-      // ---- S^T = K Q^T for 32 keys ------------------------------------------------------
-      f32x4 sacc[2][QT];
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        V8 kf[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          kf[t] = dd_as_v8<T>(dd_ld16(Ks + (cc * 32 + t * 16 + c) * KSTR + ks * 32 + g * 8));
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int j = 0; j < QT; ++j)   // first K-step accumulates onto a literal zero: no v_mov to clear sacc
-            sacc[t][j] = dd_mfma16(kf[t], qf[j][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[t][j]);
-      }
-      // ---- online softmax; lane holds keys key0 + t*16 + g*4 + r for query column c -------
-      const bool tail = key0 + 32 > p.lk;             // uniform; only the last chunk is masked
-      V8 pf[QT];
-#pragma unroll
-      for (int j = 0; j < QT; ++j) {
-        float s[8];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[t * 4 + r] = sacc[t][j][r];
-        if (tail) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (key0 + t * 16 + g * 4 + r >= p.lk) s[t * 4 + r] = -INFINITY;
-        }
-        // Lane-local max of the lane's 8 scores (scale > 0).  Deferred rescale: the running max (and
-        // the O / l accumulators) only move when SOME lane sees a score more than 2^RESCALE_THR above
-        // it; until then probabilities are taken against the old max (they may reach 2^RESCALE_THR —
-        // exact in floating point up to the usual rounding).  The cross-lane max over the four key
-        // groups (two ds_bpermute round trips on the critical path) is therefore only taken inside
-        // the rare branch; the common case needs a compare and a wave-wide `any`.
-        const float mx_l = dd_max8(s);
-        if (__any(mx_l * p.scale_log2 - m_run[j] > RESCALE_THR)) {   // wave-uniform, rare after the first tiles
-          float mx = fmaxf(mx_l, __shfl_xor(mx_l, 16, 64));
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-          const float m_new = fmaxf(m_run[j], mx * p.scale_log2);
-          const float alpha = DD_EXP2(m_run[j] - m_new);
-          m_run[j] = m_new;
-          if (!ONES) l_run[j] *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < DVT; ++dt) {
-            oacc[dt][j][0] *= alpha; oacc[dt][j][1] *= alpha;
-            oacc[dt][j][2] *= alpha; oacc[dt][j][3] *= alpha;
-          }
-        }
-        const float m_use = m_run[j];
-        float ls = 0.f;
-        V8 pv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pe = DD_EXP2(fmaf(s[e], p.scale_log2, -m_use));
-          if (!ONES) ls += pe;
-          pv[e] = (T)pe;
-        }
-        pf[j] = pv;
-        if (!ONES) l_run[j] += ls;
-      }
-      // ---- O^T += V^T P^T -----------------------------------------------------------------
-#pragma unroll
-      for (int dt = 0; dt < DVT; ++dt) {
-        V8 vf;
-        if constexpr (TR) {
-          // hardware transpose read: 16-lane group g reads a 4-key x 16-d block; lane 4q+pp
-          // supplies the address of key row q, columns 4pp..4pp+3, and receives column (lane&15).
-          const T* a0 = Vs + (cc * 32 + g * 4 + (c >> 2)) * VSTR + dt * 16 + (c & 3) * 4;
-          const T* a1 = a0 + 16 * VSTR;
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(a0));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(a1));
-          __builtin_memcpy(&vf, &lo, 8);
-          __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            vf[e] = Vs[(cc * 32 + (e >> 2) * 16 + g * 4 + (e & 3)) * VSTR + dt * 16 + c];
-        }
-#pragma unroll
-        for (int j = 0; j < QT; ++j) oacc[dt][j] = dd_mfma16(vf, pf[j], oacc[dt][j]);
-      }
-    }
-  }
-
-  // ---- finalise: O[q][d] = O^T / l ------------------------------------------------------
-  T* obase = reinterpret_cast<T*>(p.o) + (int64_t)b * p.obs + h * D;
-#pragma unroll
-  for (int j = 0; j < QT; ++j) {
-    float l;
-    if (ONES) {       // denominator = accumulator row d == D, held by lane group (D%16)/4, register D%4
-      l = __shfl(oacc[DVT - 1][j][D % 4], ((D % 16) / 4) * 16 + c, 64);
-    } else {
-      l = l_run[j];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
-    }
-    const float inv = 1.0f / l;
-    const int qrow = q0 + j * 16 + c;
-    if (qrow >= p.lq) continue;
-#pragma unroll
-    for (int dt = 0; dt < DVT; ++dt) {
-      const int d0 = dt * 16 + g * 4;
-      if (d0 >= D) continue;
-      T* dst = obase + (int64_t)qrow * p.ldo + d0;
-      float o4[4] = {oacc[dt][j][0] * inv, oacc[dt][j][1] * inv,
-                     oacc[dt][j][2] * inv, oacc[dt][j][3] * inv};
-      if (p.accumulate) {
-        V4 prev = *reinterpret_cast<const V4*>(dst);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] += (float)prev[e];
-      }
-      V4 ov;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (T)o4[e];
-      *reinterpret_cast<V4*>(dst) = ov;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// v5: same products and register layout as dd_attn_kernel, with the per-tile overhead taken out of
+// The kernel ("v5"; its register-staged round-1 predecessor dd_attn_kernel and the tuning variants 1-13 of
+// dd_attn_desc.variant were removed in round 5: no dispatcher selected them): the products and register layout of the
+// file header, with the per-tile overhead taken out of
 // the instruction stream (the d = 40 loop is VALU-issue-bound: ~45 % of its slots were bookkeeping):
 //  * K/V rows come in through buffer loads with the hardware range check — per-lane byte offsets
 //    are computed once, rows past lk read as zeros, no compare / branch per load;
@@ -696,54 +442,18 @@ int launch_attn5d(const AttnParams& p, hipStream_t s) {
   return launch_attn5<T, D, QT, KV_TILE, NBUF, WPE>(p, s);
 }
 
-template <typename T, int D, int QT, bool TR, int KV_TILE>
-int launch_attn(const AttnParams& p, hipStream_t s) {
-  constexpr int DQ = (D + 31) / 32 * 32;
-  constexpr int DVT = (D + 15) / 16;
-  constexpr size_t smem = (size_t)KV_TILE * ((DQ + 16) + (DVT * 16 + (D == 160 ? 16 : 0))) * sizeof(T);
-  const int qblk = 4 * QT * 16;
-  AttnParams pp = p;
-  pp.nqb = (p.lq + qblk - 1) / qblk;
-  dim3 grid(pp.nqb * p.batch * p.heads);
-  hipLaunchKernelGGL((dd_attn_kernel<T, D, QT, TR, KV_TILE>), grid, dim3(256), smem, s, pp);
-  return dd_check_launch();
-}
-
 template <typename T, int D>
 int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
   // 32 query rows per wave when the sequence is long enough to fill the chip, else 16;
   // 128-key tiles (half the barriers) for long key sequences at the small head dims
   const long blocks128 = (long)((p.lq + 127) / 128) * p.batch * p.heads;
   const bool qt2 = p.lq >= 256 && blocks128 >= 512;
-  if (p.kv_map2 && variant != 0) return DD_ERR_UNSUPPORTED;          // the pair exists for the default kernels only
-  if (variant == 1) {
-    return qt2 ? launch_attn<T, D, 2, false, 64>(p, s) : launch_attn<T, D, 1, false, 64>(p, s);
-  }
-  // variants 2..4: explicit (rows per wave, key tile) choices for tuning experiments
-  if (variant == 2) { if constexpr (D <= 80) return launch_attn<T, D, 1, true, 128>(p, s); }
-  if (variant == 3) return launch_attn<T, D, 2, true, 64>(p, s);
-  if (variant == 4) return launch_attn<T, D, 1, true, 64>(p, s);
-  if (variant == 13) {        // the round-1 default before the v5 family
-    if constexpr (D <= 80) {
-      if (p.lk >= 512) return qt2 ? launch_attn<T, D, 2, true, 128>(p, s) : launch_attn<T, D, 1, true, 128>(p, s);
-    }
-    return qt2 ? launch_attn<T, D, 2, true, 64>(p, s) : launch_attn<T, D, 1, true, 64>(p, s);
-  }
-  // v5 family (buffer-load K/V staging, one-time pad columns, no tail code for d = 40)
+  if (variant != 0) return DD_ERR_UNSUPPORTED;       // the tuning variants of rounds 1-3 are gone (ABI 3)
+  // K/V staging by buffer loads: 32-bit byte offsets per (batch, head) plane
   const bool v5_ok = (int64_t)p.lk * p.ldk * (int64_t)sizeof(T) < (1ll << 31) &&
                      (int64_t)p.lk * p.ldv * (int64_t)sizeof(T) < (1ll << 31);
-  if (variant >= 5 && variant <= 12 && !v5_ok) return DD_ERR_UNSUPPORTED;
-  if (p.kv_map2 && !v5_ok) return DD_ERR_UNSUPPORTED;
-  if (variant == 9) { if constexpr (D == 40) return launch_attn5<T, D, 2, 64, 1, 4>(p, s); }
-  if (variant == 10) { if constexpr (D == 40) return launch_attn5<T, D, 2, 128, 1, 4>(p, s); }
-  if (variant == 11) { if constexpr (D == 40) return launch_attn5<T, D, 3, 64, 1, 3>(p, s); }
-  if (variant == 12) { if constexpr (D == 40) return launch_attn5<T, D, 3, 128, 1, 3>(p, s); }
-  if (variant == 5) { if constexpr (D <= 80) return launch_attn5<T, D, 2, 128, 1>(p, s); }
-  if (variant == 6) { if constexpr (D <= 80) return launch_attn5<T, D, 2, 64, 2>(p, s); }
-  if (variant == 7) return launch_attn5<T, D, 2, 64, 1>(p, s);
-  if (variant == 8) return launch_attn5<T, D, 1, 64, 1>(p, s);
-  // Default: the v5 family whenever its 32-bit buffer offsets fit.
-  if (v5_ok) {
+  if (!v5_ok) return DD_ERR_UNSUPPORTED;
+  {
     if constexpr (D == 40) {
       // 32 or 48 query rows per wave (128 / 192 per workgroup).  The loop is VALU-issue-bound and only
       // reaches that bound with the SIMDs full (4 waves at 32 rows, 3 at 48), so what decides is how
@@ -768,10 +478,6 @@ int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
       return qt2 ? launch_attn5d<T, D, 2, 64, 1>(p, s) : launch_attn5d<T, D, 1, 64, 1>(p, s);
     }
   }
-  if constexpr (D <= 80) {
-    if (p.lk >= 512) return qt2 ? launch_attn<T, D, 2, true, 128>(p, s) : launch_attn<T, D, 1, true, 128>(p, s);
-  }
-  return qt2 ? launch_attn<T, D, 2, true, 64>(p, s) : launch_attn<T, D, 1, true, 64>(p, s);
 }
 
 template <typename T>

@@ -41,21 +41,16 @@ struct GemmParams {
   int g_per_tile, chunks_per_split;      // direct small-image conv (dd_conv3s_kernel)
   int band_rows, bands; float inv_bands; // ... its BAND form: output pixels per band, bands per instance
   const float* ln_colsum; const float* ln_bias; float ln_eps;   // LayerNorm fold (dd_gemm2_kernel, dense)
-  int* tile_counters;                    // split-K: per-tile arrival counters (in-kernel ordered reduction) or NULL
-  uint32_t partial_bytes;                // extent of the slab region (buffer descriptor of the sc1 slab path)
   int out_f32;                           // store fp32 instead of T
   float* stat_out;                       // [rows][n/32][2] row sum / sum of squares of the stored values, or NULL
   const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
   int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
-  const void* ln_gamma; const void* ln_beta;   // direct LayerNorm prologue of the row-panel family (T [k])
-  const float* w_scale;                  // row-panel family, fp8 weights: per-output-channel dequantisation scale (fp32 [n])
   int no_stagger;                        // conv3s A/B switch (DD_STAGGER=0)
   int persist;                           // dd_gemm2_kernel: the grid is smaller than the tile count (see the kernel)
   uint64_t* dbg_stamps;                  // DD_DBG_STAMP builds only
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
   void* ln_out; int64_t ld_ln_out;       // LayerNorm EMITTED by the epilogue of the 80x320 tile (second output)
   const void* lno_gamma; const void* lno_beta;
-  const void* pf_ptr; uint32_t pf_bytes; int pf_blocks;   // weight prefetch carried by spare workgroups (dd_prefetch_block)
 };
 
 // n / d for 0 <= n < 2^22 (host-checked: rows) and the host-side inv = 1.0f / d: (n + 0.5) * inv is never within
@@ -132,35 +127,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-// WEIGHT PREFETCH BY SPARE WORKGROUPS.  A step streams 3.3 GB of weights through the 256 MiB Infinity Cache, so every
-// launch meets its weights cold in HBM (measured: 1092x1280x1280 16.3 us with HBM-cold, 14.2 with Infinity-Cache-resident,
-// 12.4 with L2-resident weights) while HBM idles > 95 % of the time.  A launch whose grid leaves workgroup slots empty
-// (the few-row levels: 80-240 tiles on 256 CUs) carries `pf_blocks` extra workgroups at the END of its grid that only
-// READ the weights of the NEXT weight-bearing launch of the same stream (host: ops._pf_hint) — 16 B per lane, 16 loads
-// in flight — so that launch finds them in the memory-side cache.  No graph node, no stream edge (a prefetch stream
-// inside the captured step cost 4 ms); reads only, so there is nothing to synchronise.
-// MEASURED on the step: not a win at any size (-1.7 % with 32 MB / 96 workgroups, +-0.2 % with 1-2 MB / 8-16); the host
-// side does not pass hints by default (ops.PREFETCH).
-template <int THREADS>
-__device__ __forceinline__ void dd_prefetch_block(const GemmParams& p, int pb) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.pf_ptr), 0, p.pf_bytes, 0x00020000);
-  const uint32_t per = ((p.pf_bytes / (uint32_t)p.pf_blocks) + 15u) & ~15u;
-  const uint32_t beg = (uint32_t)pb * per;
-  const uint32_t end = min(p.pf_bytes, beg + per);
-  u32x4 acc = {0u, 0u, 0u, 0u};
-  for (uint32_t off = beg + threadIdx.x * 16u; off < end; off += THREADS * 16u * 16u) {
-    u32x4 v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {                 // out-of-range lanes read zeros (buffer bounds) — never past the tensor
-      const uint32_t o = off + (uint32_t)j * THREADS * 16u;
-      v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, o < end ? o : 0xFFFFFFF0u, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc |= v[j];
-  }
-  asm volatile("" ::"v"(acc[0] | acc[1] | acc[2] | acc[3]));     // keeps the loads alive; nothing is stored
-}
-
 // ---- accumulator tile -> global (shared by both kernel families) ---------------------------
 // acc[tn][tm][reg]: output row = tile row tm*16 + (lane & 15),
 //                   output col = q*(4*TN) + tn*4 + reg  (q = lane >> 4)   [non-GEGLU]
@@ -170,8 +136,7 @@ __device__ __forceinline__ void dd_prefetch_block(const GemmParams& p, int pb) {
 template <typename T, int TM, int TN, bool GEGLU>
 __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int block_m0,
                                            int block_n0, int wave_m, int wave_n, int lane, int row_end,
-                                           const float* ln_mean = nullptr, const float* ln_rstd = nullptr,
-                                           int tile_id = 0, int* lds_flag = nullptr) {
+                                           const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
   const int q = lane >> 4;
   const int c = lane & 15;
   const int row0 = block_m0 + wave_m * (TM * 16) + c;
@@ -243,18 +208,10 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
   } else {
     constexpr int NG = TN / 2;
     const int col0 = block_n0 + wave_n * (TN * 16) + q * (4 * TN);
-    if (p.partial) {                       // split-K slab: fp32 stores
-      // Two forms.  tile_counters == NULL: plain stores, dd_splitk_reduce_kernel (a second launch) adds the slabs and
-      // runs the epilogue.  tile_counters != NULL: IN-LAUNCH ordered reduction by the K-slice that arrives last at
-      // the tile's counter — the write-through recipe of the CDNA4 guide (cdna_hip_programming.md "In-launch split-K
-      // reduction", MI355X_MICROARCH.md "inter-workgroup visibility"): the slabs are stored sc1 (write-through, no
-      // release fence: the L2s of the 8 XCDs are not coherent and a buffer_wbl2 per workgroup costs more than the
-      // second launch — the round-1 form with __threadfence() ran 32 -> 66 us on the 4x7 conv), EVERY storing wave
-      // drains its stores (s_waitcnt vmcnt(0)), the workgroup barrier, ONE lane's relaxed agent-scope ticket; the
-      // workgroup whose add returns split-1 reads all slabs with sc1 loads (L1-bypassing; every load of the handed-off
-      // bytes) in slice order — bit-identical to the two-launch form whoever is last — and runs the epilogue.
-      const bool ink = p.tile_counters != nullptr;
-      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.partial_bytes, 0x00020000);
+    if (p.partial) {                       // split-K slab: fp32 stores; dd_splitk_reduce_kernel (a second launch) adds the
+      // slabs and runs the epilogue.  (An IN-LAUNCH ordered reduction by the last-arriving K-slice — write-through slabs,
+      // agent-scope ticket, sc1 loads — was built in round 3, bit-identical, 3-80 % slower on the step's 23 split-K
+      // shapes, and removed in round 5: profiles/r03_splitk_inkernel_ab.txt.)
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int row = row0 + tm * 16;
@@ -263,47 +220,12 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         for (int g8 = 0; g8 < NG; ++g8) {
           const int col = col0 + g8 * 8;
           if (col >= p.n) continue;
-          if (ink) {
-            const uint32_t off = (uint32_t)((((int64_t)blockIdx.z * p.rows + row) * p.n + col) * 4);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[g8 * 2][tm]), rs_p, off, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[g8 * 2 + 1][tm]), rs_p, off + 16, 0, 16);
-          } else {
-            float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
-            *reinterpret_cast<f32x4*>(dst) = acc[g8 * 2][tm];
-            *reinterpret_cast<f32x4*>(dst + 4) = acc[g8 * 2 + 1][tm];
-          }
+          float* dst = p.partial + ((int64_t)blockIdx.z * p.rows + row) * p.n + col;
+          *reinterpret_cast<f32x4*>(dst) = acc[g8 * 2][tm];
+          *reinterpret_cast<f32x4*>(dst + 4) = acc[g8 * 2 + 1][tm];
         }
       }
-      if (!ink) return;                    // two-launch mode: dd_splitk_reduce_kernel runs the epilogue
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores have landed
-      __syncthreads();                                      // ... and every wave is past its last LDS read
-      if (threadIdx.x == 0) {
-        const int prev = __hip_atomic_fetch_add(p.tile_counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == (int)gridDim.z - 1;
-        if (last) __hip_atomic_store(p.tile_counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stream-ordered next launch
-        *lds_flag = last;
-      }
-      __syncthreads();
-      if (!*lds_flag) return;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int rowc = min(row0 + tm * 16, p.rows - 1);
-#pragma unroll
-        for (int g8 = 0; g8 < NG; ++g8) {
-          const int colc = min(col0 + g8 * 8, p.n - 8);
-          f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-          const uint32_t off0 = (uint32_t)(((int64_t)rowc * p.n + colc) * 4);
-          const uint32_t zstride = (uint32_t)((int64_t)p.rows * p.n * 4);
-          for (int z = 0; z < (int)gridDim.z; ++z) {
-            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, off0 + (uint32_t)z * zstride, 0, 16));
-            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, off0 + (uint32_t)z * zstride + 16, 0, 16));
-            s0[0] += a[0]; s0[1] += a[1]; s0[2] += a[2]; s0[3] += a[3];
-            s1[0] += b[0]; s1[1] += b[1]; s1[2] += b[2]; s1[3] += b[3];
-          }
-          acc[g8 * 2][tm] = s0;
-          acc[g8 * 2 + 1][tm] = s1;
-        }
-      }
+      return;
     }
     // Rows are handled in (at most) two batches: per batch, phase 1 issues ALL its loads (clamped
     // addresses, nothing predicated), phase 2 does the arithmetic and the stores.  One batch would
@@ -610,8 +532,7 @@ void dd_gemm_kernel(const GemmParams p) {
     buf ^= 1;
   }
 
-  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile,
-                               reinterpret_cast<int*>(smem));
+  store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
 }
 
 // =============================================================================================
@@ -766,10 +687,6 @@ void dd_gemm2_kernel(const GemmParams p) {
   const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   DD_STAMP(0);
-  if (p.pf_blocks && (int)blockIdx.x >= (int)gridDim.x - p.pf_blocks) {        // spare workgroup: prefetch only
-    if (blockIdx.z == 0) dd_prefetch_block<64 * NW>(p, (int)blockIdx.x - ((int)gridDim.x - p.pf_blocks));
-    return;
-  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);
 
@@ -1005,34 +922,24 @@ void dd_gemm2_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  // STAGGER (workgroups of >= 8 waves: two or more waves per SIMD behind ONE barrier per K-step would read LDS
-  // together and then contend for the matrix pipe together): the second half of the waves executes the MFMAs of
-  // K-step kt-1 (operands already in registers) BEFORE the fragment reads of K-step kt, i.e. half a step out of
-  // phase with the first half, so one wave's MFMAs run beside its SIMD partner's LDS traffic.  Same arithmetic
-  // in the same order per accumulator -> bit-identical results.  Fragments are double-buffered by step parity
-  // (compile-time: the loop is unrolled by two).  The direct conv kernel uses this (5.39 -> 4.78 us per 9 steps).
-  // MEASURED on this family (tiles 16 / 20 / 26, hot graph chains): 2-9 % SLOWER than the plain schedule (L0 conv
-  // 41.4 -> 45.0 us, GEGLU 53.0 -> 55.0 us, 16800x320x1600 27.3 -> 28.7 us) — unlike the direct conv, whose steps
-  // carry 12 tap gathers per wave; and the 10-wave 160-wide tiles (168 VGPRs) would spill.  Compiled out.
-  constexpr bool STAG = false;
-  const bool late = STAG && wave >= NW / 2 && !p.no_stagger;
-  V8 wf[STAG ? 2 : 1][2][TN], xf[STAG ? 2 : 1][2][TM];
-  auto mfma_step = [&](auto par_c) __attribute__((always_inline)) {
-    constexpr int par = decltype(par_c)::value;
+  // (A staggered schedule — the second half of the waves half a K-step out of phase, as in the direct conv kernel — was
+  //  measured on tiles 16 / 20 / 26 in round 3: 2-9 % SLOWER here (L0 conv 41.4 -> 45.0 us, GEGLU 53.0 -> 55.0 us); its
+  //  code was removed in round 5.)
+  V8 wf[2][TN], xf[2][TM];
+  auto mfma_step = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
     }
     __builtin_amdgcn_s_setprio(0);
   };
   int sbase = 0;                       // ring slot of this tile's stage 0 (persistent: tiles follow each other in the ring)
   bool have_next = false;              // persistent: another tile follows, its first stages are issued from this one
-  auto kstep = [&](const int kt, auto par_c) __attribute__((always_inline)) {
-    constexpr int par = STAG ? decltype(par_c)::value : 0;
+  auto kstep = [&](const int kt) __attribute__((always_inline)) {
     // stage kt must have landed; up to NSTAGE-2 younger stages may stay in flight
     if (NSTAGE == 2) {
       wait_vmcnt<0>();
@@ -1065,9 +972,6 @@ void dd_gemm2_kernel(const GemmParams p) {
         }
       }
     }
-    if constexpr (STAG) {
-      if (late && kt > 0) mfma_step(std::integral_constant<int, par ^ 1>{});
-    }
     const int slot = (sbase + kt) % NSTAGE;
     const T* xs = ring + slot * STAGE + (wave_m * TM * 16 + frow) * BK;
     const T* ws = ring + slot * STAGE + BM * BK + (wave_n * TN * 16 + frow) * BK;
@@ -1077,32 +981,24 @@ void dd_gemm2_kernel(const GemmParams p) {
     for (int ks = 0; ks < 2; ++ks) {
       const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[par][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+      for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[par][ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
+      for (int j = 0; j < TM; ++j) xf[ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK + cofs));
     }
-    if (!late) {
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(std::integral_constant<int, par>{});
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step();
   };
   const bool persist = !CONV && p.persist != 0;
   for (;;) {
   have_next = persist && lin + (int)gridDim.x < ntiles;
   for (int kt = 0; kt < nk; kt += 2) {
-    kstep(kt, std::integral_constant<int, 0>{});
+    kstep(kt);
 #ifdef DD_DBG_STAMP
     if (kt == 0) DD_STAMP(3);                  // after the first K-step
 #endif
-    if (kt + 1 < nk) kstep(kt + 1, std::integral_constant<int, 1>{});
+    if (kt + 1 < nk) kstep(kt + 1);
   }
   DD_STAMP(4);
-  if constexpr (STAG) {
-    if (late && nk > 0) {                  // the last K-step's MFMAs of the staggered waves
-      if ((nk - 1) & 1) mfma_step(std::integral_constant<int, 1>{});
-      else mfma_step(std::integral_constant<int, 0>{});
-    }
-  }
   if constexpr (!CONV && !GEGLU && WAVES_M == 1 && WAVES_N == 10 && TM == 5 && TN == 2) {
     if (p.ln_out) {                       // whole rows in this workgroup: store out AND LayerNorm(out)
       store_tile_ln<T>(p, acc, block_m0, wave_n, lane, reinterpret_cast<float*>(smem));
@@ -1111,7 +1007,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   }
   const bool ln = !CONV && p.ln_colsum;
   store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows,
-                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr, tile, reinterpret_cast<int*>(smem));
+                               ln ? s_ln_mean : nullptr, ln ? s_ln_rstd : nullptr);
   if (!have_next) break;
   lin += (int)gridDim.x;                   // next tile of this workgroup; its first stages are already in flight
   tile = xcd_remap(lin, ntiles);
@@ -1490,11 +1386,7 @@ void dd_gemm3_kernel(const GemmParams p) {
       done = true;
     }
   }
-  if (!done) {
-    if (p.tile_counters) __syncthreads();          // in-launch split-K: the flag word of store_tile aliases the ring
-    store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows, nullptr, nullptr, tile,
-                                 reinterpret_cast<int*>(smem));
-  }
+  if (!done) store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
 #ifdef DD_DBG_STAMP
   DD_STAMP(5);
   if (threadIdx.x == 0 && p.dbg_stamps) {
@@ -1545,10 +1437,6 @@ void dd_conv3s_kernel(const GemmParams p) {
   const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   DD_STAMP(0);
-  if (p.pf_blocks && (int)blockIdx.x >= (int)gridDim.x - p.pf_blocks) {        // spare workgroup: prefetch only
-    if (blockIdx.z == 0) dd_prefetch_block<64 * NW>(p, (int)blockIdx.x - ((int)gridDim.x - p.pf_blocks));
-    return;
-  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* abuf = reinterpret_cast<T*>(smem);                 // [2][AROWS][64]
   T* wring = abuf + 2 * AROWS * BK;                     // [NSW][BN][64]
@@ -1841,8 +1729,7 @@ void dd_conv3s_kernel(const GemmParams p) {
     else drain(std::integral_constant<int, 0>{});
   }
   // rows past the tile's instances are padding
-  store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows),
-                               nullptr, nullptr, tile, reinterpret_cast<int*>(smem));
+  store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows));
 #ifdef DD_DBG_STAMP
   DD_STAMP(5);
   if (threadIdx.x == 0 && p.dbg_stamps) {
@@ -1854,327 +1741,6 @@ void dd_conv3s_kernel(const GemmParams p) {
 #endif
 }
 
-// =============================================================================================
-// Kernel family 4: ROW-PANEL GEMM for the transformer projections (dense, K = C in {320, 640, 1280}).
-//
-// The C x C / C x 3C projections of a transformer block (to_q / QKV, to_out, proj_in; 16800 .. 336 rows)
-// are far too small for the tiled families: a 64x64 tile re-reads both operands through L2 once per tile
-// and a 10-20 step K loop with a barrier per step leaves the kernel latency-bound (~11 us where the bytes
-// take 3-6).  Here ONE workgroup per CU owns a column slice of BN = 4 waves x TN x 16 outputs for a whole
-// group of rows:
-//   * its weight slice lives in REGISTERS for the kernel's lifetime — every wave keeps the MFMA fragments
-//     of its TN x 16 weight rows over the full K (TN * K/32 x 4 VGPRs: 200-320 of the 512 a one-wave-per-
-//     SIMD kernel has), loaded once by buffer loads straight from global memory;
-//   * the rows stream through LDS as PANELS of BM = TM x 16 rows x full K (LDS-DMA ring, the next panel
-//     lands while the current one is multiplied); a panel needs no K loop synchronisation at all: one
-//     counted vmcnt wait + one barrier, then K/32 MFMA steps whose only LDS traffic is the A fragments;
-//   * optional LayerNorm PROLOGUE (`ln_gamma`): the panel holds the un-normalised rows and is normalised in
-//     place (two-pass fp32 statistics, result rounded to T — the arithmetic of dd_layernorm_sub_kernel)
-//     before the MFMAs, which removes the LayerNorm launch and its HBM round trip in front of every
-//     Q / QKV projection (norm1 / norm2 / norm4 of blocks.py:150-222);
-//   * 2-D decomposition p row groups x q column slices with p * q <= 256 workgroups: per-CU bytes are
-//     |W| / q + |A| / p instead of (rows / 64) x (N / 64) tile pairs.
-// Epilogue: bias, alpha, residual, accumulate, head-major planes (+ scale) like the other families.
-// Requirements (host-checked): no a2 / conv / GEGLU / split-K / rowvec, N % BN == 0.
-// =============================================================================================
-template <typename T, int VW>
-__device__ __forceinline__ void rp_store_vec(const GemmParams& p, int64_t row, int col, float (&v)[VW]) {
-  using VT = typename std::conditional<VW == 8, u32x4, u32x2>::type;
-  T* dst;
-  if (p.hm_d) {
-    const int plane = col / p.hm_d;
-    if (plane < p.hm_planes) {
-#pragma unroll
-      for (int e = 0; e < VW; ++e) v[e] *= p.hm_scale;
-    }
-    dst = reinterpret_cast<T*>(p.out) + ((int64_t)plane * p.rows + row) * p.hm_d + (col - plane * p.hm_d);
-  } else {
-    dst = reinterpret_cast<T*>(p.out) + row * p.ldc + col;
-  }
-  T tmp[VW];
-#pragma unroll
-  for (int e = 0; e < VW; ++e) tmp[e] = (T)v[e];
-  VT pk;
-  __builtin_memcpy(&pk, tmp, sizeof(VT));
-  *reinterpret_cast<VT*>(dst) = pk;
-}
-
-template <typename T, int VW>
-__device__ __forceinline__ void rp_load_vec(const T* src, float (&f)[VW]) {
-  using VT = typename std::conditional<VW == 8, u32x4, u32x2>::type;
-  const VT raw = *reinterpret_cast<const VT*>(src);
-  T tmp[VW];
-  __builtin_memcpy(tmp, &raw, sizeof(VT));
-#pragma unroll
-  for (int e = 0; e < VW; ++e) f[e] = (float)tmp[e];
-}
-
-// fp8 (OCP e4m3fn) -> T for 8 consecutive weights: one-time conversion when the fragments are loaded
-template <typename T>
-__device__ __forceinline__ typename dd_vec<T>::v8 rp_dequant8(u32x2 raw) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typename dd_vec<T>::v8 r;
-  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[0], true);
-  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[1], true);
-  r[0] = (T)a[0]; r[1] = (T)a[1]; r[2] = (T)b[0]; r[3] = (T)b[1];
-  r[4] = (T)c[0]; r[5] = (T)c[1]; r[6] = (T)d[0]; r[7] = (T)d[1];
-  return r;
-}
-
-template <typename T, int KS, int TN, int TM, int NBUF, bool LN, bool W8 = false>
-__global__ __launch_bounds__(256)
-void dd_gemm_rp_kernel(const GemmParams p) {
-  using V8 = typename dd_vec<T>::v8;
-  constexpr int K = KS * 32;
-  constexpr int NSUB = K / 64;                     // 64-column sub-tiles of a panel
-  constexpr int BM = TM * 16;
-  constexpr int BNW = TN * 16;                     // output columns per wave
-  constexpr int BN = 4 * BNW;
-  constexpr int PANEL = BM * K;                    // elements per panel buffer
-  constexpr int PIECES = (BM / 8) * NSUB;          // 1-KB DMA pieces (8 rows x 128 B) per panel
-  constexpr int PPW = (PIECES + 3) / 4;            // per wave; surplus pieces land in a dump slot
-  constexpr int VW = (TN % 2 == 0) ? 8 : 4;        // channels per epilogue vector (16 B needs an even TN)
-  constexpr int NG = 4 * TN / VW;                  // epilogue vectors per lane and row
-  constexpr int NSTORE = TM * NG;                  // store instructions per wave and (full) panel
-  static_assert(KS % 2 == 0 && NBUF >= 2, "K must be a multiple of 64");
-  static_assert(NSTORE <= 63 && (NBUF - 1) * PPW + NSTORE <= 63, "vmcnt is a 6-bit counter");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* ring = reinterpret_cast<T*>(smem);                         // [NBUF][NSUB][BM][64], chunk-swizzled
-  T* dump = ring + NBUF * PANEL;                                // [4 waves][512]: landing zone of surplus pieces
-  T* lnv = dump + 4 * 512;                                      // [2][K]: gamma | beta
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // ---- work decomposition: (row group, column slice); slices of one row group sit on one XCD ----
-  const int nwg = gridDim.x;
-  const int unit = xcd_remap(blockIdx.x, nwg);
-  const int qn = p.tiles_n;                                     // column slices
-  const int pi = unit / qn, qi = unit - pi * qn;
-  const int panels_total = (p.rows + BM - 1) / BM;
-  const int ppg = p.k_per_split;                                // panels per row group (host: ceil)
-  const int panel0 = pi * ppg;
-  const int npan = min(ppg, panels_total - panel0);             // >= 1 by construction
-  const int col0 = qi * BN + wave * BNW;
-
-  // ---- weight fragments -> registers (issued first: the longest fetch of the kernel) ------------
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
-  const int fr = lane & 15, fq = lane >> 4;
-  V8 wreg[TN][KS];
-  {
-    // weight row permutation of the other families: lane group q ends up with 4*TN CONSECUTIVE channels
-    const int loc0 = (fr >> 2) * (4 * TN) + (fr & 3);
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n = col0 + loc0 + tn * 4;
-      if constexpr (W8) {        // fp8 weights [n][K] bytes: 8 B per lane and k-step, dequantised to T once, here
-        const uint32_t vo = n < p.n ? (uint32_t)n * (uint32_t)K + (uint32_t)fq * 8u : DD_OOB;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          wreg[tn][ks] = rp_dequant8<T>(__builtin_amdgcn_raw_buffer_load_b64(rs_w, vo + ks * 32, 0, 0));
-      } else {
-      const uint32_t vo = n < p.n ? (uint32_t)n * (uint32_t)(K * 2) + (uint32_t)fq * 16u : DD_OOB;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        wreg[tn][ks] = dd_as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(rs_w, vo + ks * 64, 0, 0));
-      }
-    }
-  }
-
-  // ---- panel DMA tables (constant per lane; a panel moves only the scalar row offset) -----------
-  const int lrow8 = lane >> 3;
-  uint32_t ptab[PPW];                               // byte offset inside a panel's source rows
-  int prow[PPW];                                    // panel row this lane fetches (-1: surplus piece)
-  int pdst[PPW];                                    // LDS element offset of the piece inside a buffer
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int pc = j * 4 + wave;
-    if (pc < PIECES) {
-      const int sub = pc / (BM / 8), rb = pc - sub * (BM / 8);
-      const int row = rb * 8 + lrow8;
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      prow[j] = row;
-      ptab[j] = (uint32_t)row * (uint32_t)p.lda * 2u + (uint32_t)sub * 128u + (uint32_t)lc * 16u;
-      pdst[j] = (sub * BM + rb * 8) * 64;
-    } else {
-      prow[j] = -1; ptab[j] = DD_OOB; pdst[j] = -1;
-    }
-  }
-  auto issue_panel = [&](int pl, int buf) __attribute__((always_inline)) {
-    const int r0 = (panel0 + pl) * BM;
-    const uint32_t so = (uint32_t)r0 * (uint32_t)p.lda * 2u;
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const bool ok = prow[j] >= 0 && r0 + prow[j] < p.rows;
-      T* dst = pdst[j] >= 0 ? ring + buf * PANEL + pdst[j] : dump + wave * 512;
-      bdma16(rs_a, ok ? ptab[j] : DD_OOB, so, dst);
-    }
-  };
-#pragma unroll
-  for (int b = 0; b < NBUF - 1; ++b)
-    if (b < npan) issue_panel(b, b);
-
-  if (LN) {                                         // gamma | beta -> LDS (read per chunk in the prologue)
-    for (int i = tid; i < 2 * K / 8; i += 256) {
-      const T* src = i < K / 8 ? reinterpret_cast<const T*>(p.ln_gamma) + i * 8
-                               : reinterpret_cast<const T*>(p.ln_beta) + (i - K / 8) * 8;
-      dd_st16(lnv + i * 8, dd_ld16(src));
-    }
-  }
-  // epilogue constants
-  const int ecol0 = col0 + fq * (4 * TN);
-  float ebias[NG][VW], escale[NG][VW];
-  if constexpr (W8) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int e = 0; e < VW; ++e) escale[g][e] = p.w_scale[ecol0 + g * VW + e];
-  }
-  if (p.bias) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.bias) + ecol0 + g * VW, ebias[g]);
-  }
-  const int fswz = (lane >> 1) & 7;
-
-  for (int pl = 0; pl < npan; ++pl) {
-    const int buf = pl % NBUF;
-    // panel pl must have landed.  Younger operations of this wave: the DMA pieces of up to NBUF-2 later
-    // panels and the NSTORE stores of the previous panel's epilogue (full panels only: a partial panel is
-    // the last one of the whole problem) — counted, so nothing drains.
-    if (pl == 0) {
-      wait_vmcnt<0>();                              // first panel + the weight fragments
-    } else {
-      const int ahead = min(npan - 1 - pl, NBUF - 2);
-      if (ahead <= 0) wait_vmcnt<NSTORE>();
-      else if (ahead == 1 || NBUF <= 3) wait_vmcnt<NSTORE + (NBUF > 2 ? 1 : 0) * PPW>();
-      else wait_vmcnt<NSTORE + (NBUF > 3 ? 2 : 0) * PPW>();
-    }
-    __builtin_amdgcn_s_barrier();                   // everyone's pieces landed; slot (pl-1) % NBUF is free
-    if (pl + NBUF - 1 < npan) issue_panel(pl + NBUF - 1, (pl + NBUF - 1) % NBUF);
-    T* ab = ring + buf * PANEL;
-
-    if (LN) {
-      // LayerNorm in place: BM/4 rows per wave, LPR lanes per row, 16-B chunks round-robin over the lanes
-      constexpr int RPW = BM / 4, LPR = 64 / RPW, NCH = K / 8;
-      const int row = wave * RPW + lane / LPR;
-      const int sub = lane % LPR;
-      const int rsw = (row >> 1) & 7;
-      auto chunk_ptr = [&](int ci) __attribute__((always_inline)) {
-        return ab + ((ci >> 3) * BM + row) * 64 + (((ci & 7) ^ rsw) << 3);
-      };
-      float s = 0.f;
-      for (int ci = sub; ci < NCH; ci += LPR) {
-        float f[8];
-        dd_unpack8<T>(dd_ld16(chunk_ptr(ci)), f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += f[e];
-      }
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      const float mean = s * (1.0f / (float)K);
-      float ss = 0.f;
-      for (int ci = sub; ci < NCH; ci += LPR) {
-        float f[8];
-        dd_unpack8<T>(dd_ld16(chunk_ptr(ci)), f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; ss += d * d; }
-      }
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-      const float rstd = rsqrtf(ss * (1.0f / (float)K) + p.ln_eps);
-      for (int ci = sub; ci < NCH; ci += LPR) {
-        float f[8], ga[8], be[8];
-        dd_unpack8<T>(dd_ld16(chunk_ptr(ci)), f);
-        dd_unpack8<T>(dd_ld16(lnv + ci * 8), ga);
-        dd_unpack8<T>(dd_ld16(lnv + K + ci * 8), be);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * ga[e] + be[e];
-        dd_st16(chunk_ptr(ci), dd_pack8<T>(f));
-      }
-      __syncthreads();
-    }
-
-    // ---- MFMAs over the whole K: A fragments from LDS, weight fragments from registers ----------
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const T* xs = ab + fr * 64;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int cofs = ((fq + 4 * (ks & 1)) ^ fswz) << 3;
-      V8 xf[TM];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = dd_as_v8<T>(dd_ld16(xs + ((ks >> 1) * BM + j * 16) * 64 + cofs));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wreg[i][ks], xf[j], acc[i][j]);
-    }
-
-    // ---- epilogue: every global read before the first store (out may alias res) ------------------
-    const int r0 = (panel0 + pl) * BM;
-    float eres[TM][NG][VW], eacc[TM][NG][VW];
-    if (p.res) {
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int64_t rowc = min(r0 + j * 16 + fr, p.rows - 1);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.res) + rowc * p.ldres + ecol0 + g * VW, eres[j][g]);
-      }
-    }
-    if (p.accumulate) {
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int64_t rowc = min(r0 + j * 16 + fr, p.rows - 1);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          rp_load_vec<T, VW>(reinterpret_cast<const T*>(p.out) + rowc * p.ldc + ecol0 + g * VW, eacc[j][g]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int row = r0 + j * 16 + fr;
-      if (row < p.rows) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          float v[VW];
-#pragma unroll
-          for (int e = 0; e < VW; ++e) {
-            const int c = g * VW + e;                    // channel inside the lane's 4*TN run
-            v[e] = acc[c >> 2][j][c & 3];
-          }
-          if constexpr (W8) {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[e] *= escale[g][e];
-          }
-          if (p.bias) {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[e] += ebias[g][e];
-          }
-#pragma unroll
-          for (int e = 0; e < VW; ++e) v[e] *= p.alpha;
-          if (p.res) {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[e] += eres[j][g][e];
-          }
-          if (p.accumulate) {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[e] += eacc[j][g][e];
-          }
-          rp_store_vec<T, VW>(p, row, ecol0 + g * VW, v);
-        }
-      }
-    }
-  }
-}
-
-// split-K: sum the fp32 partial slabs and run the fused epilogue.
 template <typename T>
 __global__ __launch_bounds__(256)
 void dd_splitk_reduce_kernel(const GemmParams p, int nsplit) {
@@ -2211,25 +1777,14 @@ constexpr TileCfg kTiles[] = {
     {14, 2, 2, 2, 4, 3, "64x128/dma3"},
     {15, 2, 2, 2, 2, 3, "64x64/dma3"},
     {16, 4, 2, 4, 4, 2, "256x128/dma2"},
-    {17, 2, 2, 4, 2, 2, "128x64/dma2"},
-    {18, 2, 2, 2, 2, 2, "64x64/dma2"},
-    {19, 2, 2, 2, 2, 4, "64x64/dma4"},
     {20, 4, 2, 4, 4, 3, "256x128/dma3"},
-    // deep rings for cold-weight streaming (few rows, long K): most of a block's K range in flight
-    {21, 2, 2, 2, 2, 6, "64x64/dma6"},
-    {22, 2, 2, 2, 2, 8, "64x64/dma8"},
     {23, 2, 2, 4, 2, 4, "128x64/dma4"},
     {24, 2, 2, 2, 4, 4, "64x128/dma4"},
-    {25, 2, 2, 4, 4, 4, "128x128/dma4"},
-    // tall tiles for the 4x7 / 7x13 levels (336 / 1092 rows x 1280 x up to 23040): all (or a third of)
-    // the rows in one tile so the 29-59 MB weight matrix is streamed once, not once per 128 rows
-    {26, 4, 2, 6, 2, 2, "384x64/dma2"},
     // 160-wide tiles (10 waves = 2 x 5): every channel count of this network (320, 640, 960, 1280, 1920, 2560) is
     // a multiple of 160, so no column of the tile multiplies padding (a 128-wide tile wastes 1/6 of its MFMAs at
     // N = 320 and 16800 rows / 160 = 105 row tiles x 2 = 210 workgroups fill the chip in ONE generation)
     {27, 2, 5, 5, 2, 2, "160x160/dma2"},
     {28, 2, 5, 5, 2, 3, "160x160/dma3"},
-    {29, 2, 5, 5, 4, 2, "160x320/dma2"},            // GEGLU: 160 gated outputs per tile (h | g rows interleaved)
     // 80 WHOLE rows of a 320-wide output per workgroup (1 x 10 waves): the only tile whose epilogue can emit
     // LayerNorm(out) as a second tensor (dd_gemm_desc.ln_out); 16800 rows -> 210 workgroups, one generation
     {40, 1, 10, 5, 2, 2, "80x320/dma2"},
@@ -2255,26 +1810,19 @@ constexpr TileCfg kTiles[] = {
     // stages >= 100: pipelined LDS-DMA family (dd_gemm3_kernel, round 5; dense only), ring depth = stages - 100
     {72, 2, 2, 3, 2, 103, "96x64/p3"},             // 60 KB: two workgroups per CU
     {73, 2, 2, 3, 2, 105, "96x64/p5"},             // deeper rings: one workgroup per CU, cold weights 3-4 K-steps ahead
-    {74, 2, 2, 3, 2, 106, "96x64/p6"},
     {75, 4, 2, 3, 4, 103, "192x128/p3"},
     {76, 2, 2, 1, 2, 104, "32x64/p4"},
     {77, 2, 2, 1, 2, 106, "32x64/p6"},
     {78, 2, 5, 5, 2, 103, "160x160/p3"},
-    {79, 2, 2, 1, 2, 108, "32x64/p8"},
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
     {39, 4, 2, 6, 2, -3, "conv3s band 384x64"},   // stages == -3: BAND form (images larger than the tile: 28x50 level)
-    {33, 2, 2, 6, 2, -1, "conv3s 192x64/w8"},
     {34, 2, 2, 6, 2, -1, "conv3s 192x64/w4"},
     {35, 2, 2, 4, 2, -1, "conv3s 128x64/w3"},     // 72 KB of LDS: two workgroups per CU
-    {36, 2, 2, 4, 4, -1, "conv3s 128x128/w3"},
     {37, 2, 2, 6, 2, -1, "conv3s 192x64/g3"},     // taps in groups of three: one barrier per 72 MFMAs
-    {38, 2, 2, 4, 2, -1, "conv3s 128x64/g3"},
-    // stages == -2: row-panel family (dd_gemm_rp_kernel; dense, K in {320, 640, 1280}): tm = 16-row MFMA blocks
-    // per panel; wn / tn follow from K (5 x 16 columns per wave at K = 320, 2 x 16 otherwise)
-    {41, 1, 4, 1, 0, -2, "rowpanel 16"},
-    {42, 1, 4, 2, 0, -2, "rowpanel 32"},
+    // (Round 5 removed what no entry of the tracked table used: 64x64 rings of 2 / 4 / 6 / 8 slots, 128x64 / 128x128 with
+    //  2 / 4, 384x64, the GEGLU-only 160x320, three direct-conv variants, and the round-2 row-panel family.)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2301,9 +1849,6 @@ bool dma_ok(const dd_gemm_desc* d) {
   }
   return ok;
 }
-
-// row-panel family: 16-column MFMA blocks per wave for a given K (0 = K not covered)
-inline int rp_tn(int k) { return k == 320 ? 5 : (k == 640 || k == 1280) ? 2 : 0; }
 
 Plan make_plan(const dd_gemm_desc* d) {
   const bool geglu = d->epilogue == DD_EPI_GEGLU;
@@ -2338,32 +1883,6 @@ Plan make_plan(const dd_gemm_desc* d) {
     if (d->tile > 0 && d->tile != 40) { pl.unsupported = true; return pl; }
     for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 40) ti = i;
     if (d->n != 320 || !dma_ok(d)) { pl.unsupported = true; return pl; }
-  }
-  if ((d->ln_gamma || d->w_scale) && (ti < 0 || kTiles[ti].stages != -2)) {   // LayerNorm prologue / fp8 weights: row-panel family only
-    if (d->tile > 0) { pl.unsupported = true; return pl; }
-    for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 41) ti = i;
-  }
-  if (kTiles[ti].stages == -2) {                     // row-panel GEMM
-    const TileCfg& t = kTiles[ti];
-    const int tn = rp_tn(d->k);
-    const int bn = 4 * tn * 16, bm = t.tm * 16;
-    const bool ok = tn > 0 && !d->conv && !d->a2 && !geglu && d->epilogue == DD_EPI_NONE && !d->rowvec &&
-                    !d->ln_colsum && !d->ln_stats_out && !d->out_f32 && d->split_k <= 1 && (d->n % bn) == 0 &&
-                    (t.tm == 1 || d->k <= 640) && (!d->ln_gamma || d->ln_beta) &&
-                    (int64_t)d->rows * d->lda < ((int64_t)1 << 30) && (int64_t)d->n * d->k < ((int64_t)1 << 30);
-    if (!ok) { pl.unsupported = true; return pl; }
-    const int panels = ceil_div(d->rows, bm);
-    const int q = d->n / bn;
-    int pg = kNumCU / q;
-    if (pg < 1) pg = 1;
-    if (pg > panels) pg = panels;
-    const int ppg = ceil_div(panels, pg);
-    pl.tile_idx = ti;
-    pl.tiles_m = ceil_div(panels, ppg);
-    pl.tiles_n = q;
-    pl.split = 1;
-    pl.k_per_split = ppg;                            // panels per row group
-    return pl;
   }
   if (kTiles[ti].stages == -3) {                     // direct conv on row BANDS with a halo (images larger than the tile)
     const TileCfg& t = kTiles[ti];
@@ -2464,23 +1983,6 @@ int launch_cfg(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
-// Spare workgroups for the weight prefetch: only when every tile of the launch is resident at once and at least 8 slots
-// stay empty; ~64 KB in flight per 256-thread workgroup, one workgroup per 128 KB of weights, at most 96.
-static int dd_prefetch_blocks(const GemmParams& p, const void* kern, int threads, size_t smem, int blocks,
-                              std::atomic<int>& resident) {
-  if (!p.pf_ptr || !p.pf_bytes || p.persist) return 0;
-  int per_cu = resident.load(std::memory_order_relaxed);
-  if (per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, smem) != hipSuccess || per_cu < 1) per_cu = 1;
-    resident.store(per_cu, std::memory_order_relaxed);
-  }
-  const int spare = kNumCU * per_cu - blocks;
-  if (spare < 8) return 0;
-  const int want = (int)((p.pf_bytes + (128u << 10) - 1) / (128u << 10)) * 256 / threads;
-  static const int cap = getenv("DD_PF_MAX_BLOCKS") ? atoi(getenv("DD_PF_MAX_BLOCKS")) : 96;
-  return std::max(std::min(8, cap), std::min(std::min(spare, cap), want));
-}
-
 template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool CONV, bool GEGLU>
 int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -2490,15 +1992,6 @@ int launch_cfg2(const GemmParams& p, const Plan& pl, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
-  static std::atomic<int> pf_resident{0};
-  const int pf = dd_prefetch_blocks(p, reinterpret_cast<const void*>(kern), 64 * WM * WN, smem, (int)grid.x * pl.split, pf_resident);
-  if (pf) {                                // spare workgroups at the end of the grid read the next launch's weights
-    GemmParams q = p;
-    q.pf_blocks = pf;
-    grid.x += pf;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, q);
-    return dd_check_launch();
-  }
   if constexpr (!CONV) {
     if (pl.persist_ok) {                 // more tiles than resident workgroups: walk them with the ring running ahead
       static std::atomic<int> resident{0};
@@ -2543,90 +2036,26 @@ int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
   dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.split);
-  static std::atomic<int> pf_resident{0};
-  const int pf = dd_prefetch_blocks(p, reinterpret_cast<const void*>(kern), 64 * WM * WN, smem, (int)grid.x * pl.split, pf_resident);
-  if (pf) {
-    GemmParams q = p;
-    q.pf_blocks = pf;
-    grid.x += pf;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, q);
-    return dd_check_launch();
-  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, p);
   return dd_check_launch();
 }
 
-template <typename T, int KS, int TN, int TM, int NBUF>
-int launch_rp(const GemmParams& p, const Plan& pl, hipStream_t s) {
-  constexpr size_t smem = ((size_t)NBUF * TM * 16 * KS * 32 + 4 * 512 + 2 * KS * 32) * sizeof(T);
-  static_assert(smem <= 160 * 1024, "LDS");
-  dim3 grid(pl.tiles_m * pl.tiles_n);
-  if (p.w_scale) {             // fp8 weights (with or without the LayerNorm prologue)
-    if (p.ln_gamma) {
-      auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, true, true>;
-      static std::atomic<uint64_t> attr_done{0};
-      dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
-      hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
-    } else {
-      auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, false, true>;
-      static std::atomic<uint64_t> attr_done{0};
-      dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
-      hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
-    }
-    return dd_check_launch();
-  }
-  if (p.ln_gamma) {
-    auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, true>;
-    static std::atomic<uint64_t> attr_done{0};
-    dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
-  } else {
-    auto kern = dd_gemm_rp_kernel<T, KS, TN, TM, NBUF, false>;
-    static std::atomic<uint64_t> attr_done{0};
-    dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
-  }
-  return dd_check_launch();
-}
-
-template <typename T>
-int launch_rp_k(const GemmParams& p, const Plan& pl, hipStream_t s) {
-  const int tm = kTiles[pl.tile_idx].tm;
-  switch (p.k) {
-    case 320: return tm == 1 ? launch_rp<T, 10, 5, 1, 3>(p, pl, s) : launch_rp<T, 10, 5, 2, 3>(p, pl, s);
-    case 640: return tm == 1 ? launch_rp<T, 20, 2, 1, 3>(p, pl, s) : launch_rp<T, 20, 2, 2, 3>(p, pl, s);
-    case 1280: if (tm == 1) return launch_rp<T, 40, 2, 1, 3>(p, pl, s); break;
-  }
-  return DD_ERR_UNSUPPORTED;
-}
-
 template <typename T, bool CONV, bool GEGLU>
 int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
-#ifndef DD_DBG_ONLY_P        // -DDD_DBG_ONLY_P: a quick-to-compile build with the pipelined family only (reading its ISA)
-  if (kTiles[pl.tile_idx].stages == -2) {
-    if constexpr (!CONV && !GEGLU) return launch_rp_k<T>(p, pl, s);
-    return DD_ERR_UNSUPPORTED;
-  }
-#endif
   switch (kTiles[pl.tile_idx].id) {
-#ifndef DD_DBG_ONLY_P
+#ifndef DD_DBG_ONLY_P        // -DDD_DBG_ONLY_P: a quick-to-compile build with the pipelined family only (reading its ISA)
     case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
     case 39: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5, 1, true>(p, pl, s); break;
-    case 33: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 8>(p, pl, s); break;
     case 34: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 4>(p, pl, s); break;
     case 35: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 3>(p, pl, s); break;
-    case 36: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 4, 3>(p, pl, s); break;
     case 37: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 6, 3>(p, pl, s); break;
-    case 38: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 6, 3>(p, pl, s); break;
 #endif
     case 72: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false>(p, pl, s); break;
     case 73: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
-    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 6, false>(p, pl, s); break;
     case 75: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 3, 4, 3, GEGLU>(p, pl, s); break;
     case 76: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false>(p, pl, s); break;
     case 77: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 6, false>(p, pl, s); break;
     case 78: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
-    case 79: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 8, false>(p, pl, s); break;
 #ifndef DD_DBG_ONLY_P
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
@@ -2635,15 +2064,8 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 20: return launch_cfg2<T, 4, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
     case 13: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 3, CONV, false>(p, pl, s); break;
     case 15: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 3, CONV, false>(p, pl, s); break;
-    case 17: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 2, CONV, false>(p, pl, s); break;
-    case 18: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 2, CONV, false>(p, pl, s); break;
-    case 19: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 4, CONV, false>(p, pl, s); break;
-    case 21: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 6, CONV, false>(p, pl, s); break;
-    case 22: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 2, 2, 8, CONV, false>(p, pl, s); break;
     case 23: if constexpr (!GEGLU) return launch_cfg2<T, 2, 2, 4, 2, 4, CONV, false>(p, pl, s); break;
     case 24: return launch_cfg2<T, 2, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
-    case 25: return launch_cfg2<T, 2, 2, 4, 4, 4, CONV, GEGLU>(p, pl, s);
-    case 26: if constexpr (!GEGLU) return launch_cfg2<T, 4, 2, 6, 2, 2, CONV, false>(p, pl, s); break;
     case 27: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 2, CONV, false>(p, pl, s); break;
     case 28: if constexpr (!GEGLU) return launch_cfg2<T, 2, 5, 5, 2, 3, CONV, false>(p, pl, s); break;
     case 40: if constexpr (!GEGLU && !CONV) return launch_cfg2<T, 1, 10, 5, 2, 2, false, false>(p, pl, s); break;
@@ -2653,7 +2075,6 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 50: return launch_cfg2<T, 2, 4, 8, 4, 2, CONV, GEGLU>(p, pl, s);
     case 44: return launch_cfg2<T, 4, 2, 3, 4, 3, CONV, GEGLU>(p, pl, s);
     case 46: return launch_cfg2<T, 4, 2, 3, 4, 2, CONV, GEGLU>(p, pl, s);
-    case 29: if constexpr (GEGLU) return launch_cfg2<T, 2, 5, 5, 4, 2, false, true>(p, pl, s); break;   // 168 VGPRs: only the GEGLU form fits without spills
     case 1: return launch_cfg<T, 2, 2, 4, 4, CONV, GEGLU>(p, pl, s);
     case 3: return launch_cfg<T, 2, 2, 2, 4, CONV, GEGLU>(p, pl, s);
     case 5: return launch_cfg<T, 4, 2, 4, 4, CONV, GEGLU>(p, pl, s);
@@ -2668,7 +2089,7 @@ template <typename T>
 int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hipStream_t s) {
   int rc = DD_OK;
   if (d->phase == 2) {                      // reduce launch only (per-launch timing of a split-K GEMM)
-    if (pl.split <= 1 || p.tile_counters) return DD_OK;
+    if (pl.split <= 1) return DD_OK;
   } else if (d->epilogue == DD_EPI_GEGLU) {
     if (d->conv) return DD_ERR_UNSUPPORTED;
     rc = launch_tile<T, false, true>(p, pl, s);
@@ -2678,7 +2099,7 @@ int launch_dtype(const dd_gemm_desc* d, const GemmParams& p, const Plan& pl, hip
     rc = launch_tile<T, false, false>(p, pl, s);
   }
   if (rc != DD_OK) return rc;
-  if (pl.split > 1 && !p.tile_counters && d->phase != 1) {
+  if (pl.split > 1 && d->phase != 1) {
     const int64_t total = (int64_t)p.rows * (p.n / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -2696,23 +2117,13 @@ int validate(const dd_gemm_desc* d) {
     if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
     if (!dd_aligned16(d->ln_colsum) || !dd_aligned16(d->ln_bias) || (d->lda & 7)) return DD_ERR_BAD_ARG;
   }
-  if (d->ln_gamma) {                                   // direct LayerNorm prologue (row-panel family)
-    if (!d->ln_beta || d->conv || d->a2 || d->ln_colsum) return DD_ERR_BAD_ARG;
-    if (!dd_aligned16(d->ln_gamma) || !dd_aligned16(d->ln_beta) || (d->lda & 7)) return DD_ERR_BAD_ARG;
-    if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
-  }
   if (d->ln_out) {                                     // LayerNorm emitted by the epilogue (80x320 tile)
     if (!d->lno_gamma || !d->lno_beta || d->conv || d->epilogue != DD_EPI_NONE || d->rowvec || d->accumulate ||
-        d->out_f32 || d->out_headmajor_d || d->ln_stats_out || d->ln_colsum || d->ln_gamma || d->w_scale)
+        d->out_f32 || d->out_headmajor_d || d->ln_stats_out || d->ln_colsum)
       return DD_ERR_UNSUPPORTED;
     if (d->n != 320) return DD_ERR_UNSUPPORTED;
     if (!dd_aligned16(d->ln_out) || !dd_aligned16(d->lno_gamma) || !dd_aligned16(d->lno_beta) || (d->ld_ln_out & 7))
       return DD_ERR_BAD_ARG;
-  }
-  if (d->w_scale) {                                    // fp8 weights (row-panel family)
-    if (d->conv || d->a2 || d->ln_colsum || d->epilogue != DD_EPI_NONE) return DD_ERR_UNSUPPORTED;
-    if (d->k != 320 && d->k != 640 && d->k != 1280) return DD_ERR_UNSUPPORTED;
-    if (!dd_aligned16(d->w_scale)) return DD_ERR_BAD_ARG;
   }
   if (d->rows <= 0 || d->n <= 0 || d->k <= 0) return DD_ERR_BAD_ARG;
   if (d->rows >= (1 << 22)) return DD_ERR_UNSUPPORTED;         // dd_fdiv's exactness bound (largest real case: 1.08 M)
@@ -2756,20 +2167,10 @@ thread_local char g_kname[160];
 extern "C" int dd_gemm_num_tiles(void) { return kNumTiles; }
 extern "C" int dd_gemm_tile_id(int index) { return (index >= 0 && index < kNumTiles) ? kTiles[index].id : -1; }
 
-// Split-K workspace layout: [DD_COUNTER_BYTES of per-tile arrival counters][split fp32 slabs].  The
-// counter region must be zero when the workspace is first handed in; every launch leaves it zero.
+// Split-K workspace layout: [DD_COUNTER_BYTES, reserved][split fp32 slabs].  The reserved head held the arrival counters
+// of the in-launch reduction (round 3, removed in round 5: slower than the reduce launch on every split-K shape of the
+// step); the slab offset is kept because dd_groupnorm_splitk's callers address the slabs behind it.
 constexpr int64_t DD_COUNTER_BYTES = 65536;
-// In-kernel reduction is OFF by default: the device-scope release / acquire it needs (the L2s of the
-// 8 XCDs are not coherent: buffer_wbl2 + buffer_inv per workgroup) costs far more than the second
-// launch — 4x7 conv 32 -> 66 us, whole step 73.5 -> 69.1 steps/s.  DD_SPLITK_INKERNEL=1 enables it.
-bool inkernel_reduce(const dd_gemm_desc* d, const Plan& pl) {
-  // per call: dd_gemm_desc.splitk_inkernel (the tuner times both forms); DD_SPLITK_INKERNEL=1 / 0 forces it on / off
-  static const int force = getenv("DD_SPLITK_INKERNEL") ? atoi(getenv("DD_SPLITK_INKERNEL")) : -1;
-  const bool want = force >= 0 ? force == 1 : d->splitk_inkernel != 0;
-  const int64_t slab_bytes = (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
-  return want && slab_bytes < ((int64_t)1 << 32) &&
-         (int64_t)pl.tiles_m * pl.tiles_n * (int64_t)sizeof(int) <= DD_COUNTER_BYTES;
-}
 
 extern "C" int64_t dd_gemm_workspace_bytes(const dd_gemm_desc* d) {
   if (validate(d) != DD_OK) return 0;
@@ -2783,34 +2184,27 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   const Plan pl = make_plan(d);
   if (pl.unsupported) return "unsupported";
   const TileCfg& t = kTiles[pl.tile_idx];
-  if (t.stages == -2) {
-    snprintf(g_kname, sizeof(g_kname), "dd_gemm_rp_kernel<%s, %d, %d, %d, 3, %s> split=1 grid=%dx%d tile=%s",
-             d->dtype == DD_F16 ? "_Float16" : "__bf16", d->k / 32, rp_tn(d->k), t.tm, d->ln_gamma ? "true" : "false",
-             pl.tiles_m, pl.tiles_n, t.name);
-    return g_kname;
-  }
   if (t.stages < 0) {
     const bool band = t.stages == -3;
-    const int nsw = (t.id == 31 || band) ? 5 : (t.id == 33 ? 8 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4)));
-    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d ink=%d grid=%dx%d tile=%s",
+    const int nsw = (t.id == 31 || band) ? 5 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4));
+    snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
              d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, nsw, (t.id >= 37 && !band) ? 3 : 1,
-             band ? "true" : "false", pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)), pl.tiles_m, pl.tiles_n, t.name);
+             band ? "true" : "false", pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   if (t.stages >= 100) {
-    snprintf(g_kname, sizeof(g_kname), "dd_gemm3_kernel<%s, %d, %d, %d, %d, %d, %s> split=%d ink=%d grid=%dx%d tile=%s",
+    snprintf(g_kname, sizeof(g_kname), "dd_gemm3_kernel<%s, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
              d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.stages - 100,
-             d->epilogue == DD_EPI_GEGLU ? "true" : "false", pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)),
-             pl.tiles_m, pl.tiles_n, t.name);
+             d->epilogue == DD_EPI_GEGLU ? "true" : "false", pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
   // demangled template-argument form, as rocprofv3 prints the kernel symbol
   char stage[16] = "";
   if (t.stages) snprintf(stage, sizeof(stage), " %d,", t.stages);
-  snprintf(g_kname, sizeof(g_kname), "dd_gemm%s_kernel<%s, %d, %d, %d, %d,%s %s, %s> split=%d ink=%d grid=%dx%d tile=%s",
+  snprintf(g_kname, sizeof(g_kname), "dd_gemm%s_kernel<%s, %d, %d, %d, %d,%s %s, %s> split=%d grid=%dx%d tile=%s",
            t.stages ? "2" : "", d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, stage,
            d->conv ? "true" : "false", d->epilogue == DD_EPI_GEGLU ? "true" : "false",
-           pl.split, (int)(pl.split > 1 && inkernel_reduce(d, pl)), pl.tiles_m, pl.tiles_n, t.name);
+           pl.split, pl.tiles_m, pl.tiles_n, t.name);
   return g_kname;
 }
 
@@ -2824,15 +2218,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.ln_colsum = reinterpret_cast<const float*>(d->ln_colsum);
   p.ln_bias = reinterpret_cast<const float*>(d->ln_bias);
   p.ln_eps = d->ln_eps;
-  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta;
-  p.w_scale = reinterpret_cast<const float*>(d->w_scale);
   p.ln_out = d->ln_out; p.ld_ln_out = d->ld_ln_out; p.lno_gamma = d->lno_gamma; p.lno_beta = d->lno_beta;
-  p.pf_ptr = nullptr; p.pf_bytes = 0; p.pf_blocks = 0;
-  if (d->prefetch && d->prefetch_bytes >= (64 << 10) && dd_aligned16(d->prefetch)) {
-    p.pf_ptr = d->prefetch;                                   // the launchers decide whether spare workgroups exist
-    static const int64_t cap_mb = getenv("DD_PF_MAX_MB") ? atoi(getenv("DD_PF_MAX_MB")) : 32;
-    p.pf_bytes = (uint32_t)std::min<int64_t>(d->prefetch_bytes, cap_mb << 20) & ~15u;
-  }
   p.a = d->a; p.a2 = d->a2; p.lda = d->lda; p.lda2 = d->lda2;
   p.k1 = d->a2 ? d->k1 : d->k;
   p.rows = d->rows; p.n = d->n; p.k = d->k;
@@ -2864,7 +2250,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.inv_rpi = 1.0f / (float)p.rows_per_inst;
   {
     const int64_t nw = (d->epilogue == DD_EPI_GEGLU ? 2 : 1) * (int64_t)d->n;
-    p.w_bytes = (uint32_t)(nw * d->k * (d->w_scale ? 1 : 2));
+    p.w_bytes = (uint32_t)(nw * d->k * 2);
     if (d->conv) {
       p.a_bytes = (uint32_t)((int64_t)d->rows / (d->hout * d->wout) * d->hin * d->win * d->cin * 2);
       p.a2_bytes = 0;
@@ -2882,7 +2268,6 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   }
   p.persist = 0;
   p.partial = nullptr;
-  p.tile_counters = nullptr;
   p.dbg_stamps = nullptr;
 #ifdef DD_DBG_STAMP
   if (d->ws && d->ws_bytes >= (4 << 20))
@@ -2892,8 +2277,6 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
     const int64_t need = DD_COUNTER_BYTES + (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
     if (!d->ws || d->ws_bytes < need) return DD_ERR_WORKSPACE;
     p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(d->ws) + DD_COUNTER_BYTES);
-    p.partial_bytes = (uint32_t)std::min<int64_t>((int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float), 0xFFFFFFFFll);
-    if (inkernel_reduce(d, pl)) p.tile_counters = reinterpret_cast<int*>(d->ws);
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();

@@ -262,162 +262,9 @@ void dd_gn_apply_kernel(const GnParams p) {
   }
 }
 
-// ---- ONE launch for the big images too: statistics and apply around a grid-wide barrier ------------------------
-// The 28x50 level does not fit the single-launch form below (a block per (instance, 40 channels) would be 96 blocks
-// streaming 112 KB each: 19.6 us) and pays two launches and a second read of x (7.2 + 9.6 us).  Here a block owns
-// (instance, pixel range, ALL channels) exactly as in the two-launch form, but keeps its <= NV vectors per thread in
-// registers: partial sums -> sc1 (write-through) stores -> grid barrier -> every block combines the partials of its
-// instance in a fixed order -> normalise + SiLU from the registers.  One read of x, one launch.
-// The barrier needs every block of the grid resident at once: the host only takes this path while the grid is far
-// below the chip's slot count even with a launch on each of the step's three streams (gn_coop_plan), the spin is
-// bounded and a timeout is recorded in the workspace instead of hanging the GPU (bar[2]).
-// Visibility across the 8 XCDs follows the write-through recipe of the in-launch split-K reduction (gemm.hip).
-template <typename T, int NV>
-__global__ __launch_bounds__(GN_THREADS)
-void dd_gn_coop_kernel(const GnParams p, unsigned* bar) {
-  __shared__ float s_a0[GN_THREADS], s_b0[GN_THREADS], s_a1[GN_THREADS], s_b1[GN_THREADS];
-  __shared__ int s_g0[GN_THREADS], s_g1[GN_THREADS];
-  __shared__ float s_mean[64], s_rstd[64];
-  const int split = blockIdx.x, inst = blockIdx.y;
-  const GnMap mp = gn_map(p.c);                      // host: c / 8 <= GN_THREADS -> one channel vector per thread
-  const int p0 = split * p.pix_per_split;
-  const int p1 = min(p.hw, p0 + p.pix_per_split);
-  const int ch = mp.cv << 3;
-  const float my_pivot = (int)threadIdx.x < p.groups ? gn_pivot<T>(p, inst, threadIdx.x) : 0.f;
-  u32x4 v[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int px = p0 + mp.pl + i * mp.pl_count;
-    v[i] = (mp.active && px < p1) ? dd_ld16(gn_src<T>(p, (int64_t)inst * p.hw + px, ch)) : u32x4{0u, 0u, 0u, 0u};
-  }
-  int g0 = -1, g1 = -1;
-  float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
-  if (mp.active) {
-    float s[8], ss[8], pv[8];
-    const int ga = ch / p.cpg, gb = min((ch + 7) / p.cpg, p.groups - 1);
-    const float pa = gn_pivot<T>(p, inst, ga), pb = gn_pivot<T>(p, inst, gb);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; pv[e] = (ch + e) / p.cpg == ga ? pa : pb; }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      if (p0 + mp.pl + i * mp.pl_count < p1) {
-        float f[8];
-        dd_unpack8<T>(v[i], f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; ss[e] += d * d; }
-      }
-    }
-    g0 = ga;
-    const int gl = (ch + 7) / p.cpg;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool first = (ch + e) / p.cpg == g0;
-      a0 += first ? s[e] : 0.f;  b0 += first ? ss[e] : 0.f;
-      a1 += first ? 0.f : s[e];  b1 += first ? 0.f : ss[e];
-    }
-    g1 = gl != g0 ? gl : -1;
-  }
-  s_g0[threadIdx.x] = g0; s_a0[threadIdx.x] = a0; s_b0[threadIdx.x] = b0;
-  s_g1[threadIdx.x] = g1; s_a1[threadIdx.x] = a1; s_b1[threadIdx.x] = b1;
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      p.ws, 0, (uint32_t)((size_t)p.m * GN_MAX_SPLIT * p.groups * 2 * sizeof(float)), 0x00020000);
-  if ((int)threadIdx.x < p.groups) {                 // fixed-order sum of the threads whose vector can overlap group g
-    const int g = threadIdx.x;
-    float gsum = 0.f, gsq = 0.f;
-    const int lo = (g * p.cpg) >> 3;
-    const int hi = min(((g + 1) * p.cpg - 1) >> 3, mp.cv_count - 1);
-    for (int pl = 0; pl < mp.pl_count; ++pl) {
-      for (int c = lo; c <= hi; ++c) {
-        const int t = pl * mp.cv_count + c;
-        if (s_g0[t] == g) { gsum += s_a0[t]; gsq += s_b0[t]; }
-        if (s_g1[t] == g) { gsum += s_a1[t]; gsq += s_b1[t]; }
-      }
-    }
-    const uint32_t off = (uint32_t)((((int64_t)inst * p.nsplit + split) * p.groups + g) * 2 * sizeof(float));
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gsum), rs_w, off, 0, 16);       // sc1: write-through
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, gsq), rs_w, off + 4, 0, 16);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
-  __syncthreads();
-  // ---- grid barrier (sense reversal on bar[1]; bar[0] returns to 0 for the next launch) ----
-  if (threadIdx.x == 0) {
-    const unsigned nblocks = gridDim.x * gridDim.y;
-    const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == nblocks - 1) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      int spins = 0;
-      while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 21)) {                   // ~ 0.2 s: some block never became resident — record it, do not hang
-          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // A block that gave up waiting must not normalise with incomplete sums: every block re-reads the flag
-  // and, when it is set, writes NaN over its piece — a wrong launch is LOUD (bench.py's outputs_finite, every parity
-  // test) instead of silently off.  ops.groupnorm also checks bar[2] outside capture.
-  const bool gn_timed_out = __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-  {
-    // combine the per-split partial sums of this instance: chunk-strided sc1 loads, then one thread per group adds
-    // the chunk sums in a fixed order (bit-reproducible)
-    const int g = threadIdx.x % p.groups;
-    const int chunk = threadIdx.x / p.groups;
-    const int nchunk = GN_THREADS / p.groups;
-    float s = 0.f, ss = 0.f;
-    if (chunk < nchunk) {
-      const uint32_t base = (uint32_t)(((int64_t)inst * p.nsplit * p.groups + g) * 2 * sizeof(float));
-      for (int i = chunk; i < p.nsplit; i += nchunk) {
-        const uint32_t off = base + (uint32_t)i * p.groups * 2 * sizeof(float);
-        s += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, off, 0, 16));
-        ss += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, off + 4, 0, 16));
-      }
-    }
-    s_a0[threadIdx.x] = s;
-    s_b0[threadIdx.x] = ss;
-    __syncthreads();
-    if ((int)threadIdx.x < p.groups) {
-      float a = 0.f, b = 0.f;
-      for (int c = 0; c < nchunk; ++c) { a += s_a0[c * p.groups + threadIdx.x]; b += s_b0[c * p.groups + threadIdx.x]; }
-      const float inv_n = 1.0f / ((float)p.hw * (float)p.cpg);
-      const float dm = a * inv_n;                        // mean - pivot
-      const float var = fmaxf(b * inv_n - dm * dm, 0.f);
-      s_mean[threadIdx.x] = my_pivot + dm;
-      s_rstd[threadIdx.x] = rsqrtf(var + p.eps);
-    }
-  }
-  __syncthreads();
-  if (!mp.active) return;
-  float ga[8], be[8], sc[8], sh[8];
-  dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.gamma) + ch), ga);
-  dd_unpack8<T>(dd_ld16(reinterpret_cast<const T*>(p.beta) + ch), be);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int g = (ch + e) / p.cpg;
-    sc[e] = s_rstd[g] * ga[e];
-    sh[e] = be[e] - s_mean[g] * sc[e];
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int px = p0 + mp.pl + i * mp.pl_count;
-    if (px < p1) {
-      float f[8];
-      dd_unpack8<T>(v[i], f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float y = f[e] * sc[e] + sh[e];
-        f[e] = gn_timed_out ? __builtin_nanf("") : (p.silu ? dd_silu_f(y) : y);
-      }
-      dd_st16(reinterpret_cast<T*>(p.y) + ((int64_t)inst * p.hw + px) * p.c + ch, dd_pack8<T>(f));
-    }
-  }
-}
+// (A cooperative ONE-launch form for the big images — statistics, grid barrier, apply — was built in round 3 and
+//  measured 2 % slower on the step, 0.4 % slower in the single-stream decoder alone (profiles/r03_gn_coop_ab.txt,
+//  r04_experiments.txt #4: the barrier costs what the second launch cost); removed in round 5.)
 
 // ---- single-launch GroupNorm for slabs that fit the register file --------------------------------
 // One block owns (instance, `cpb` channels = whole groups) and keeps its hw x cpb slab in registers
@@ -710,40 +557,11 @@ int gn_plan(int hw, int c, int* pix_per_split) {
   return (hw + pps - 1) / pps;
 }
 
-// Cooperative single launch (dd_gn_coop_kernel): one channel vector per thread, <= 16 pixel vectors per thread in
-// registers, and a grid small enough that a launch on each of the step's three streams is resident at the same time
-// with room to spare (256 CUs x >= 5 blocks of <= 100 VGPRs = 1280 slots).  DD_GN_COOP=0: off; DD_GN_COOP_MAX=<blocks>.
-// MEASURED ON THE STEP: 2 % SLOWER than the two launches (82.9 vs 84.6 steps/s, four alternating pairs on one box): with
-// three streams in flight the blocks of a launch become resident over a long window, the early ones hold their slots
-// spinning, and nothing of the second phase can start before the last one arrived.  OFF by default (DD_GN_COOP=1 or
-// dd_groupnorm_set_coop(1) turn it on).
-std::atomic<int> g_gn_coop{-1};
-bool gn_coop_plan(int m, int hw, int c, int* pix_per_split, int* nsplit, int* nv) {
-  int on = g_gn_coop.load(std::memory_order_relaxed);
-  if (on < 0) {
-    on = getenv("DD_GN_COOP") ? atoi(getenv("DD_GN_COOP")) : 0;
-    g_gn_coop.store(on, std::memory_order_relaxed);
-  }
-  static const int max_blocks = getenv("DD_GN_COOP_MAX") ? atoi(getenv("DD_GN_COOP_MAX")) : 400;
-  const int cv = c / 8;
-  if (!on || cv > GN_THREADS || cv < 1) return false;
-  const int pl = GN_THREADS / cv;
-  for (int n = 8; n <= 16; n += 8) {
-    const int pps = pl * n;
-    const int ns = (hw + pps - 1) / pps;
-    // 8 vectors: 84 VGPRs -> 5 blocks per CU (1280 slots, 3 x 400 fit); 16 vectors: 132 VGPRs -> 3 per CU (768 slots, 3 x 250 fit)
-    if (ns > GN_MAX_SPLIT || ns * m > (n == 8 ? max_blocks : max_blocks * 5 / 8)) continue;
-    *pix_per_split = pps; *nsplit = ns; *nv = n;
-    return true;
-  }
-  return false;
-}
-
 }  // namespace
 
 extern "C" int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups) {
   if (m <= 0 || groups <= 0) return 0;
-  return (int64_t)m * GN_MAX_SPLIT * groups * 2 * (int64_t)sizeof(float) + 256;     // + barrier state of the cooperative form
+  return (int64_t)m * GN_MAX_SPLIT * groups * 2 * (int64_t)sizeof(float) + 256;     // + 256 B reserved head (ABI 2 layout)
 }
 
 extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int32_t c2,
@@ -765,9 +583,7 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
   p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.c = c;
   p.gamma = gamma; p.beta = beta; p.y = y;
   p.m = m; p.hw = hw; p.groups = groups; p.cpg = c / groups; p.eps = eps; p.silu = apply_silu;
-  // the first 256 B of the workspace are the cooperative form's barrier state (count, generation, timeout flag): a FIXED
-  // place, zero when the buffer is created and left at zero / monotone by every launch; the partial sums follow
-  p.ws = reinterpret_cast<float*>(ws) + 64;
+  p.ws = reinterpret_cast<float*>(ws) + 64;          // the first 256 B stay reserved; the partial sums follow
   p.nsplit = gn_plan(hw, c, &p.pix_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();
@@ -780,19 +596,6 @@ extern "C" int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int
     } else {
       if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_fused_kernel<_Float16, 1024, GNF_NV_BIG>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
       else hipLaunchKernelGGL((dd_gn_fused_kernel<__bf16, 1024, GNF_NV_BIG>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
-    }
-    return dd_check_launch();
-  }
-  int cnv = 0;
-  if (gn_coop_plan(m, hw, c, &p.pix_per_split, &p.nsplit, &cnv)) {
-    unsigned* bar = reinterpret_cast<unsigned*>(ws);
-    dim3 cgrid(p.nsplit, m);
-    if (cnv == 8) {
-      if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_coop_kernel<_Float16, 8>), cgrid, dim3(GN_THREADS), 0, s, p, bar);
-      else hipLaunchKernelGGL((dd_gn_coop_kernel<__bf16, 8>), cgrid, dim3(GN_THREADS), 0, s, p, bar);
-    } else {
-      if (dtype == DD_F16) hipLaunchKernelGGL((dd_gn_coop_kernel<_Float16, 16>), cgrid, dim3(GN_THREADS), 0, s, p, bar);
-      else hipLaunchKernelGGL((dd_gn_coop_kernel<__bf16, 16>), cgrid, dim3(GN_THREADS), 0, s, p, bar);
     }
     return dd_check_launch();
   }
@@ -837,13 +640,6 @@ extern "C" int dd_groupnorm_splitk(const float* partial, int32_t nsplit, const v
     else hipLaunchKernelGGL((dd_gn_fused_kernel<__bf16, 1024, GNF_NV_BIG, true>), fgrid, dim3(1024), 0, s, p, cpb, vpp, plc, nv, kred);
   }
   return dd_check_launch();
-}
-
-extern "C" void dd_groupnorm_set_coop(int32_t on) { g_gn_coop.store(on ? 1 : 0, std::memory_order_relaxed); }
-
-extern "C" int dd_groupnorm_is_coop(int32_t m, int32_t hw, int32_t c) {
-  int pps, ns, nv;
-  return m > 0 && hw > 0 && c > 0 && !(c & 7) && gn_coop_plan(m, hw, c, &pps, &ns, &nv) ? 1 : 0;
 }
 
 extern "C" int dd_groupnorm_is_fused(int32_t hw, int32_t c, int32_t groups) {

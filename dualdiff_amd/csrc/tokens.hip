@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256)
 void dd_box_tokens_kernel(const TI* pts, const int64_t* classes, const uint8_t* masks, const T* class_tokens,
                           const T* null_pos, const T* null_cls, T* pos, T* cat, T* cls_out, int rows, int npts,
                           FourierFreqs2 fr, int nf, int inc, int ctd, int64_t ld_cat, int cls_off, int normalize,
-                          float mn0, float mn1, float mn2, float rg0, float rg1, float rg2) {
+                          float mn0, float mn1, float mn2, float rg0, float rg1, float rg2, int n_classes) {
   const int r = blockIdx.x;
   if (r >= rows) return;
   const bool keep = masks ? masks[r] != 0 : true;
@@ -130,9 +130,14 @@ void dd_box_tokens_kernel(const TI* pts, const int64_t* classes, const uint8_t* 
     }
   }
   // class-token part: 16-byte vectors
-  const T* src = keep ? class_tokens + (int64_t)classes[r] * ctd : null_cls;
+  // class index as torch indexing takes it: negative wraps once; what is still out of range (a padding value on a kept
+  // row) must not read foreign memory: its tokens become NaN (torch would raise a device assert)
+  int64_t ci = keep ? classes[r] : 0;
+  if (n_classes > 0 && ci < 0) ci += n_classes;
+  const bool bad = keep && n_classes > 0 && (ci < 0 || ci >= n_classes);
+  const T* src = keep && !bad ? class_tokens + ci * ctd : null_cls;
   for (int i = threadIdx.x; i < ctd / 8; i += blockDim.x) {
-    const u32x4 v = dd_ld16(src + i * 8);
+    const u32x4 v = bad ? u32x4{0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu} : dd_ld16(src + i * 8);
     dd_st16(cat + (int64_t)r * ld_cat + cls_off + i * 8, v);
     if (cls_out) dd_st16(cls_out + (int64_t)r * ctd + i * 8, v);
   }
@@ -191,7 +196,7 @@ int launch_box(const dd_box_tokens_desc* d, const FourierFreqs2& fr, hipStream_t
                      d->masks, (const T*)d->class_tokens, (const T*)d->null_pos, (const T*)d->null_class, (T*)d->pos,
                      (T*)d->cat, (T*)d->cls_out, d->rows, d->points_per_box, fr, d->num_freqs, d->include_input ? 1 : 0,
                      d->class_token_dim, d->ld_cat, d->cls_offset, d->normalize ? 1 : 0, d->xyz_min[0], d->xyz_min[1],
-                     d->xyz_min[2], d->xyz_range[0], d->xyz_range[1], d->xyz_range[2]);
+                     d->xyz_min[2], d->xyz_range[0], d->xyz_range[1], d->xyz_range[2], d->n_classes);
   return dd_check_launch();
 }
 
@@ -239,7 +244,7 @@ extern "C" int dd_fourier_embed_strided(const void* x, void* out, int64_t rows, 
 extern "C" int dd_box_tokens(const dd_box_tokens_desc* d, dd_stream_t stream) {
   if (!d || !d->points || !d->classes || !d->class_tokens || !d->null_pos || !d->null_class || !d->pos || !d->cat)
     return DD_ERR_BAD_ARG;
-  if (d->rows <= 0 || d->points_per_box <= 0 || d->num_freqs <= 0 || d->class_token_dim <= 0) return DD_ERR_BAD_ARG;
+  if (d->rows <= 0 || d->points_per_box <= 0 || d->num_freqs <= 0 || d->class_token_dim <= 0 || d->n_classes < 0) return DD_ERR_BAD_ARG;
   if (d->num_freqs > 16 || (d->class_token_dim & 7) || (d->cls_offset & 7) || (d->ld_cat & 7)) return DD_ERR_UNSUPPORTED;
   if (d->ld_cat < d->cls_offset + d->class_token_dim) return DD_ERR_BAD_ARG;
   if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;

@@ -43,6 +43,23 @@ def fold_lora_(model, lora_state_dict, scale=1.0, network_alphas=None):
            and k[: -len("_lora.up.weight")] + suffix_down not in lora_state_dict]
     if ups:
         raise KeyError("LoRA up-weights without a down-weight: %s" % ups[:4])
+    # `network_alphas` as diffusers' loaders hand it over: keys '<prefix>.<attention path>.processor.<proj>_lora.down.weight
+    # .alpha', '<...>.<proj>_lora.alpha' or the bare stem, with an optional 'unet.' prefix — normalised to the stem;
+    # entries that match no folded pair are an error (a silently ignored alpha is a silently wrong LoRA scale)
+    alphas = {}
+    for k, v in (network_alphas or {}).items():
+        kk = k[len("unet."):] if k.startswith("unet.") else k
+        for suf in (".alpha", ".network_alpha"):
+            if kk.endswith(suf):
+                kk = kk[: -len(suf)]
+        for suf in ("_lora.down.weight", "_lora.up.weight", "_lora"):
+            if kk.endswith(suf):
+                kk = kk[: -len(suf)]
+        if ".processor." not in kk and kk.rsplit(".", 1)[-1] in ("to_q", "to_k", "to_v", "to_out"):
+            path, proj = kk.rsplit(".", 1)
+            kk = path + ".processor." + proj
+        alphas[kk] = v
+    used = set()
     plan = []                                # validate EVERYTHING first: a bad entry must not leave a half-folded model
     for key, down in lora_state_dict.items():
         if not key.endswith(suffix_down):
@@ -69,9 +86,13 @@ def fold_lora_(model, lora_state_dict, scale=1.0, network_alphas=None):
         # alpha key convention: `<stem>_lora.alpha` or `<stem>_lora.network_alpha` beside the down / up pair (a 0-d or
         # 1-element tensor, or a number); a separate mapping goes through `network_alphas`
         alpha = lora_state_dict.get(stem + "_lora.alpha", lora_state_dict.get(stem + "_lora.network_alpha"))
-        if alpha is None and network_alphas:
-            alpha = network_alphas.get(stem, network_alphas.get(stem + "_lora.down.weight"))
+        if alpha is None and stem in alphas:
+            alpha = alphas[stem]
+            used.add(stem)
         plan.append((attn, lin, down, up, float(scale) * (float(alpha) / rank if alpha is not None else 1.0)))
+    unmatched = sorted(set(alphas) - used)
+    if unmatched:
+        raise KeyError("network_alphas entries that match no LoRA pair of the state dict: %s" % unmatched[:4])
     n = 0
     with torch.no_grad():
         for attn, lin, down, up, factor in plan:

@@ -207,7 +207,7 @@ class BasicMultiviewTransformerBlock(BasicTransformerBlock):
             nb = len(maps)
         # connector(to_out(...)) as one GEMM with the residual add (folded weights, see _folded_out)
         w, b = self._folded_out(nb)
-        if layers.LN_PRODUCER and w.shape[0] == 320 and layers.LN_FOLD == "0" and not layers.LN_DIRECT:   # emits norm3(out) as well
+        if layers.LN_PRODUCER and w.shape[0] == 320 and layers.LN_FOLD == "0":   # emits norm3(out) as well
             out = O.gemm(o, w, b, res=h, ln_out=(self.norm3.weight, self.norm3.bias, self.norm3.eps))
             out._ln_cache = (self.norm3, out._ln_out)
             return out

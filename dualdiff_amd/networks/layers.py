@@ -89,12 +89,16 @@ class Linear(_Cached):
     def wx(self):
         """The (320, 320) weight in the layout dd_xattn320 streams (ops.xattn_pack_weight), packed lazily like w2d and
         owned by this module."""
-        if "_pk_wx" not in self.__dict__:
-            self.__dict__["_pk_wx"] = O.xattn_pack_weight(self.w2d)
-        return self.__dict__["_pk_wx"]
+        # w2d of a 320 x 320 layer ALIASES the live parameter, so an in-place update (optimizer step, weight.mul_) is seen
+        # by the three-launch path at once; the packed copy follows through the parameter's version counter (re-packed
+        # outside a capture only: a graph that recorded the old buffer keeps it alive and consistent with itself)
+        ver = (self.weight.data_ptr(), self.weight._version)
+        hit = self.__dict__.get("_pk_wx")
+        if hit is None or (hit[1] != ver and not torch.cuda.is_current_stream_capturing()):
+            hit = self.__dict__["_pk_wx"] = (O.xattn_pack_weight(self.w2d), ver)
+        return hit[0]
 
-    fp8 = False        # extension (BASELINE configs[4]): multiply by e4m3fn weights + per-channel scales
-    fp8_mfma = False   # extension: W8A8 on the fp8 matrix path (dd_gemm8) where it pays: K >= 640 and a wide output
+    fp8_mfma = False   # extension (BASELINE configs[4]): W8A8 on the fp8 matrix path (dd_gemm8) where it pays: K >= 640, wide output
 
     @property
     def w8p(self):
@@ -102,17 +106,6 @@ class Linear(_Cached):
         if "_pk_w8p" not in self.__dict__:
             self.__dict__["_pk_w8p"] = O.quantize_fp8_padded(self.w2d)
         return self.__dict__["_pk_w8p"]
-
-    @property
-    def w8(self):
-        """(float8_e4m3fn [n, k], fp32 scale [n]) of this layer's weight, packed lazily like w2d."""
-        if "_pk_w8" not in self.__dict__:
-            self.__dict__["_pk_w8"] = O.quantize_fp8(self.w2d)
-        return self.__dict__["_pk_w8"]
-
-    def _fp8_ok(self, kw):
-        return (self.fp8 and O.rowpanel_ok(self.in_features, self.out_features) and kw.get("a2") is None
-                and kw.get("epilogue", O.DD_EPI_NONE) == O.DD_EPI_NONE and not kw.get("ln_stats"))
 
     def run(self, x2d, ln_next=None, **kw):
         """x2d: (rows, K) — fused-epilogue GEMM (see ops.gemm kwargs).  ln_next: the LayerNorm module that will
@@ -123,30 +116,20 @@ class Linear(_Cached):
             out = O.gemm(x2d, w, self.bias, ln_out=(ln_next.weight, ln_next.bias, ln_next.eps), **kw)
             out._ln_cache = (ln_next, out._ln_out)
             return out
-        if self._fp8_ok(kw):
-            w8, sc = self.w8
-            return O.gemm(x2d, w8, self.bias, w_scale=sc, **kw)
         w = self.w2d
         if w.shape[1] != self.in_features:   # K padded to a multiple of 8 (e.g. cam2token 189 -> 192)
             x2d = torch.nn.functional.pad(x2d, (0, w.shape[1] - x2d.shape[1]))
         return O.gemm(x2d, w, self.bias, **kw)
 
     def run_ln(self, x2d, norm, **kw):
-        """LayerNorm(norm) + this Linear.  Row-panel GEMM with the LayerNorm as its prologue where the family
-        covers the shape (ln_direct_ok), else the algebraic fold when enabled, else two launches."""
+        """LayerNorm(norm) + this Linear: the algebraic fold when enabled, else two launches.  (The row-panel GEMM with
+        the LayerNorm as its prologue — round 2, 9 % slower on the step — went with its family in round 5.)"""
         if self.fp8_mfma and fp8_mfma_ok(norm, self.in_features, self.out_features, x2d) \
                 and set(kw) <= {"epilogue"} and kw.get("epilogue", O.DD_EPI_NONE) in (O.DD_EPI_NONE, O.DD_EPI_GEGLU):
             # the LayerNorm launch quantises its output rows to e4m3; the projection runs on the fp8 matrix path
             a8, sa = O.rowquant_fp8(x2d, (norm.weight, norm.bias, norm.eps))
             w8, sw = self.w8p
             return O.gemm8(a8, sa, w8, sw, self.bias, dtype=x2d.dtype, geglu=kw.get("epilogue") == O.DD_EPI_GEGLU)
-        if ln_direct_ok(norm, self.in_features, self.out_features, kw):
-            if self._fp8_ok(kw):
-                w8, sc = self.w8
-                return O.gemm(x2d, w8, self.bias, w_scale=sc, ln_direct=(norm.weight, norm.bias, norm.eps), **kw)
-            return O.gemm(x2d, self.w2d, self.bias, ln_direct=(norm.weight, norm.bias, norm.eps), **kw)
-        if self._fp8_ok(kw) and isinstance(norm, LayerNorm):
-            return self.run(norm.run(x2d), **kw)
         if not ln_fold_ok(norm, self.in_features, self.out_features, x2d):
             return self.run(norm.run(x2d), **kw)
         w, ln = fold_layernorm(self.__dict__, "_pk_ln", norm, [self.weight], [self.bias])
@@ -272,15 +255,6 @@ def want_ln_stats():
     return LN_FOLD == "stats"
 
 
-# LayerNorm as the PROLOGUE of the row-panel projection GEMM (dd_gemm_desc.ln_gamma): the panel of un-normalised
-# rows is normalised in LDS before the MFMAs, so norm1 / norm2 / norm4 need no launch of their own and their
-# output never visits HBM.  Correct and parity-tested, but MEASURED SLOWER on config 2 (73.9 vs 81.2 steps/s
-# fp16): a workgroup owns a 128..320-column slice, so the LayerNorm of a row panel is recomputed by every
-# column slice (x5 .. x30 at C = 640 / 1280), and with one wave per SIMD the LayerNorm (VALU), MFMA and
-# epilogue (memory) phases of a panel do not overlap.  Off by default; DD_LN_DIRECT=1 enables it.
-LN_DIRECT = __import__("os").environ.get("DD_LN_DIRECT", "0") == "1"
-
-
 # LayerNorm emitted by the PRODUCER's epilogue (dd_gemm_desc.ln_out): the GEMM that writes the residual stream at
 # the 320-channel level runs on a tile owning whole rows (80 x 320) and writes LayerNorm(out) next to out, so the
 # next sub-layer's norm needs no launch and does not re-read the stream.  DD_LN_PRODUCER=0 turns it off.
@@ -288,13 +262,13 @@ LN_PRODUCER = __import__("os").environ.get("DD_LN_PRODUCER", "1") != "0"
 
 
 def ln_producer_ok(lin, norm, kw):
-    if not LN_PRODUCER or not isinstance(norm, LayerNorm) or lin.out_features != 320 or lin.fp8:
+    if not LN_PRODUCER or not isinstance(norm, LayerNorm) or lin.out_features != 320:
         return False
-    if LN_FOLD != "0" or LN_DIRECT:            # the consumer would fold / recompute the LayerNorm and ignore ln_out
+    if LN_FOLD != "0":                         # the consumer would fold the LayerNorm and ignore ln_out
         return False
     if lin.w2d.shape[1] % 64 or kw.get("a2") is not None and kw["a2"].shape[1] % 64:
         return False
-    bad = ("ln", "ln_direct", "ln_stats", "head_major", "out_f32", "accumulate", "rowvec", "out", "tile", "split_k")
+    bad = ("ln", "ln_stats", "head_major", "out_f32", "accumulate", "rowvec", "out", "tile", "split_k")
     return not any(kw.get(k) for k in bad) and kw.get("epilogue", O.DD_EPI_NONE) == O.DD_EPI_NONE \
         and kw.get("alpha", 1.0) == 1.0
 
@@ -305,14 +279,6 @@ def fp8_mfma_ok(norm, k, n, x2d):
     (K padded 320 -> 384, three K steps) do not gain and stay 16-bit."""
     return isinstance(norm, LayerNorm) and k in (640, 1280) and n >= 3 * k and x2d.is_contiguous() \
         and getattr(x2d, "_ln_cache", None) is None
-
-
-def ln_direct_ok(norm, k, n, kw=None):
-    if not LN_DIRECT or LN_FOLD != "0" or not isinstance(norm, LayerNorm):
-        return False
-    if kw and (kw.get("epilogue", O.DD_EPI_NONE) != O.DD_EPI_NONE or kw.get("ln_stats") or kw.get("a2") is not None):
-        return False
-    return O.rowpanel_ok(k, n)
 
 
 # Fused cross-attention kernel of the 320-channel level (dd_xattn320: to_q -> SDPA over <= 128 context keys -> to_out +
@@ -510,14 +476,7 @@ class Attention(_Cached):
                 m.bias.detach() if m.bias is not None else m.weight.new_zeros(m.out_features) for m in mods]).contiguous()
         return self.__dict__[key]
 
-    fp8 = False        # extension: fused Q|K|V projection with e4m3fn weights (enable_fp8_weights)
-    fp8_mfma = False   # extension: ... and e4m3fn activations on the fp8 matrix path (enable_fp8_weights(mfma=True))
-
-    def _fused_fp8(self, names):
-        key = "_pk_w8_" + "".join(names)
-        if key not in self.__dict__:
-            self.__dict__[key] = O.quantize_fp8(self._fused(names))
-        return self.__dict__[key]
+    fp8_mfma = False   # extension: fused Q|K|V projection as W8A8 on the fp8 matrix path (enable_fp8_weights)
 
     def _hm(self, planes):
         """head_major argument of the projection GEMMs: [rows][D] planes per head, the Q planes carrying
@@ -537,16 +496,7 @@ class Attention(_Cached):
             w8, sw = self.__dict__[key]
             a8, sa = O.rowquant_fp8(x2d, (norm.weight, norm.bias, norm.eps))
             return O.gemm8(a8, sa, w8, sw, self._fused_bias(names), head_major=hm, dtype=x2d.dtype)
-        if self.fp8 and O.rowpanel_ok(x2d.shape[1], 3 * self.inner_dim):
-            w8, sc = self._fused_fp8(names)
-            if norm is not None and ln_direct_ok(norm, x2d.shape[1], 3 * self.inner_dim):
-                return O.gemm(x2d, w8, self._fused_bias(names), w_scale=sc, head_major=hm,
-                              ln_direct=(norm.weight, norm.bias, norm.eps))
-            return O.gemm(x2d if norm is None else norm.run(x2d), w8, self._fused_bias(names), w_scale=sc, head_major=hm)
         if norm is not None:
-            if ln_direct_ok(norm, x2d.shape[1], 3 * self.inner_dim):
-                return O.gemm(x2d, self._fused(("to_q", "to_k", "to_v")), self._fused_bias(("to_q", "to_k", "to_v")),
-                              ln_direct=(norm.weight, norm.bias, norm.eps), head_major=hm)
             if not ln_fold_ok(norm, x2d.shape[1], 3 * self.inner_dim, x2d):
                 return O.gemm(norm.run(x2d), self._fused(("to_q", "to_k", "to_v")),
                               self._fused_bias(("to_q", "to_k", "to_v")), head_major=hm)
@@ -586,7 +536,7 @@ class Attention(_Cached):
         if kv is None:
             kv = self.project_kv(ctx2d)
         if XATTN_FUSED and O.xattn320_ok(c, self.heads, lk, x2d.shape[0]) and self.to_q.in_features == c and self.to_q.bias is None \
-                and not self.fp8 and not ln_stats and LN_FOLD == "0" and not LN_DIRECT:
+                and not ln_stats and LN_FOLD == "0":
             # 28x50 level: q-projection, attention over the <= 128 context keys and out-projection + residual in ONE
             # launch (csrc/xattn.hip); it owns whole rows, so it also emits the next sub-layer's LayerNorm
             xn = x2d if norm is None else norm.run(x2d)
@@ -608,32 +558,26 @@ class Attention(_Cached):
                               attention_mask=attention_mask, **kw)
 
 
-def enable_fp8_weights(model, on=True, mfma=False):
-    """EXTENSION (BASELINE configs[4], no reference semantics).  Two forms:
-
-    mfma=False (round 2): every attention projection of `model` whose shape the row-panel GEMM family covers (fused
-    Q|K|V, to_q, to_out — K = C of the level) multiplies by e4m3fn weights with per-output-channel scales; fragments are
-    dequantised once when they enter registers, the matrix instruction is the 16-bit one.
-
-    mfma=True (round 3, "CDNA4 fp8 MFMA"): W8A8 — the LayerNorm in front of the fused Q|K|V projections (attn1, attn4,
-    the video block's attn_temp) and of the GEGLU projection quantises its output rows to e4m3fn (dd_rowquant_fp8) and
-    the projection runs on v_mfma_scale_f32_16x16x128_f8f6f4 (dd_gemm8), wherever that is faster than the 16-bit pair
-    (K = 640 / 1280, output >= 3 K wide: fp8_mfma_ok); everything else stays 16-bit.
+def enable_fp8_weights(model, on=True, mfma=True):
+    """EXTENSION (BASELINE configs[4], no reference semantics): W8A8 — the LayerNorm in front of the fused Q|K|V
+    projections (attn1, attn4, the video block's attn_temp) and of the GEGLU projection quantises its output rows to
+    e4m3fn (dd_rowquant_fp8) and the projection runs on v_mfma_scale_f32_16x16x128_f8f6f4 (dd_gemm8), wherever that is
+    faster than the 16-bit pair (K = 640 / 1280, output >= 3 K wide: fp8_mfma_ok); everything else stays 16-bit.
+    (The round-2 weights-only form — e4m3fn weights dequantised in registers by the row-panel GEMM family, mfma=False —
+    was removed with that family in round 5.)
 
     Quantisation happens lazily from the CURRENT weights, so fold LoRA deltas first (dualdiff_amd.lora.fold_lora_).
     Returns the number of attention layers switched."""
+    if not mfma:
+        raise NotImplementedError("the weights-only fp8 form (row-panel GEMM family) was removed in round 5; use mfma=True")
     n = 0
     for mod in model.modules():
         if isinstance(mod, Attention):
-            mod.fp8 = bool(on) and not mfma
-            mod.fp8_mfma = bool(on) and bool(mfma)
+            mod.fp8_mfma = bool(on)
             mod._drop_cache()
-            for lin in (mod.to_q, mod.to_out[0]):
-                lin.fp8 = bool(on) and not mfma
-                lin._drop_cache()
             n += 1
         elif isinstance(mod, GEGLU):
-            mod.proj.fp8_mfma = bool(on) and bool(mfma)
+            mod.proj.fp8_mfma = bool(on)
             mod.proj._drop_cache()
     return n
 

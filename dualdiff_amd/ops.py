@@ -156,10 +156,6 @@ def load_tuned(path):
 
 
 _COLD = _os.environ.get("DD_AUTOTUNE_COLD", "1") != "0"
-# Offer the in-launch split-K reduction (dd_gemm_desc.splitk_inkernel) to the tuner: OFF by default — measured on the
-# step's 23 split-K shapes (tools/splitk_ab.py, cold weights) it is bit-identical but 3-80 % SLOWER than the second
-# launch (853 -> 1108 us summed): the last-arriving slice reads split x 32-96 KB of slabs alone at the cross-XCD rate.
-_INKERNEL = _os.environ.get("DD_TUNE_INKERNEL", "0") == "1"
 # DD_TUNE_CHALLENGE=52[,..]: tiles added after the tracked table was written are timed against every entry's incumbent
 # the first time its shape is met (bench.py --challenge-tiles writes the table back)
 CHALLENGE_TILES = tuple(int(t) for t in _os.environ.get("DD_TUNE_CHALLENGE", "").split(",") if t.strip())
@@ -217,7 +213,7 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
         challenge = tuple((c, sp, 0) for c in CHALLENGE_TILES for sp in sorted({1, max(1, int(hit[1]))}))
     elif not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0, 0, 0
-    saved = (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes, d.splitk_inkernel)
+    saved = (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes)
     scratch = torch.empty(out_shape, dtype=dtype, device=device)
     d.out, d.ldc, d.accumulate = scratch.data_ptr(), scratch.stride(0), 0
     kt = (d.k + 63) // 64
@@ -228,8 +224,8 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
     if _TILES is None:
         _TILES = tuple(lib.dd_gemm_tile_id(i) for i in range(lib.dd_gemm_num_tiles()))
 
-    def timed(tile, split, iters, ink=0):
-        d.tile, d.split_k, d.splitk_inkernel = tile, split, ink
+    def timed(tile, split, iters, ink=0):          # ink: third entry of a table row (split-K form), always 0 since round 5
+        d.tile, d.split_k = tile, split
         need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
         if need > 0:
             ws = workspace(need, device)
@@ -267,7 +263,7 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
             t = timed(tile, split, 21, ink)
             if t is not None and t < 0.97 * best_t:          # a challenger must win by 3 %: the medians carry ~2 % of noise
                 best, best_t = (tile, split, ink), t
-        (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes, d.splitk_inkernel) = saved
+        (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
         if best != tuple(hit):
             print("[tune] %s: %s -> %s (%.1f -> %.1f us)" % (key, tuple(hit), best, t_inc * 1e3, best_t * 1e3), flush=True)
         _TUNED[key] = best
@@ -280,7 +276,7 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
         for split in _SPLITS:
             if split > 1 and (d.epilogue == DD_EPI_GEGLU or kt < 4 * split or blocks128 * split > 4096):
                 continue
-            for ink in ((0, 1) if split > 1 and _INKERNEL else (0,)):       # split-K: two launches / in-launch reduction
+            for ink in (0,):
                 t = timed(tile, split, 3, ink)            # >= 3 samples per candidate, cold or hot
                 if t is not None:
                     cands.append((t, tile, split, ink))
@@ -290,7 +286,7 @@ def _autotune(lib, d, key, out_shape, dtype, device, warm=()):
         t2 = timed(tile, split, 15 if _COLD else 12, ink)
         if t2 is not None and t2 < best_t:
             best, best_t = (tile, split, ink), t2
-    (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes, d.splitk_inkernel) = saved
+    (d.out, d.ldc, d.accumulate, d.tile, d.split_k, d.ws, d.ws_bytes) = saved
     _TUNED[key] = best
     return best
 
@@ -359,7 +355,7 @@ def workspace(nbytes, device, kind="gemm"):
 def _kname(lib, d):
     full = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
     name, rest = full.split(" split=")
-    return name, int(rest.split(" ")[0]), " ink=1" in rest
+    return name, int(rest.split(" ")[0])
 
 
 def _staged_bytes(lib, d):
@@ -373,7 +369,7 @@ def _staged_bytes(lib, d):
         return 0.0
     tiles = int(m.group(1)) * int(m.group(2))
     t = re.search(r"(\d+)x(\d+)", m.group(3))
-    if t is None or "rowpanel" in m.group(3):
+    if t is None:
         return 0.0
     bm, bn = int(t.group(1)), int(t.group(2))
     if "conv3s" in m.group(3):
@@ -383,52 +379,12 @@ def _staged_bytes(lib, d):
     return float(tiles) * ksteps * (bm + bn) * 128.0
 
 
-# Weight prefetch hints (dd_gemm_desc.prefetch): every weight-bearing launch learns which weights followed it on its
-# stream the last time round (the step repeats the same sequence) and offers them to the spare workgroups of its grid.
-# Hints hold a weak reference to the next weight tensor and are dropped when it died or moved.
-# MEASURED, NOT A WIN (profiles/r03_prefetch_ab.txt, same box, alternating): off 87.6 steps/s; 32 MB / 96 workgroups 85.5
-# (-1.7 % in a first series against 87.0); 8 MB / 64 87.2; 4 MB / 32 87.4; 2 MB / 16 87.7; 1 MB / 8 87.8 — the reading
-# workgroups cost what the warmer weights save.  OFF by default; DD_WEIGHT_PREFETCH=1 (+ DD_PF_MAX_MB / DD_PF_MAX_BLOCKS).
-PREFETCH = _os.environ.get("DD_WEIGHT_PREFETCH", "0") == "1"
-_PF_LAST, _PF_NEXT = {}, {}
-
-
-def _pf_hint(d, w):
-    if not PREFETCH:
-        return
-    import weakref
-    ptr = w.data_ptr()
-    sid = torch.cuda.current_stream().cuda_stream
-    last = _PF_LAST.get(sid)
-    if last is not None and last != ptr:
-        if len(_PF_NEXT) > 20000:
-            _PF_NEXT.clear()
-        try:
-            _PF_NEXT[last] = (weakref.ref(w), ptr, w.numel() * w.element_size())
-        except TypeError:
-            pass
-    _PF_LAST[sid] = ptr
-    nxt = _PF_NEXT.get(ptr)
-    if nxt is None:
-        return
-    t = nxt[0]()
-    if t is None or t.data_ptr() != nxt[1]:
-        del _PF_NEXT[ptr]
-        return
-    d.prefetch, d.prefetch_bytes = nxt[1], nxt[2]
-
-
 def _timed_gemm(lib, d, what, suffix, flops, nbytes, rows, n):
     """dd_gemm under the KernelTimer: a split-K GEMM's two launches are bracketed SEPARATELY (dd_gemm_desc.phase)
     and booked under their own kernel symbols, so that every class of the roofline table is one kernel symbol
     whose average duration can be checked against rocprofv3's."""
-    name, split, ink = _kname(lib, d)
+    name, split = _kname(lib, d)
     staged = _staged_bytes(lib, d)
-    if split > 1 and ink:        # ONE launch: partial slabs written through + read back by the last-arriving slices
-        e0 = _TIMER.start()
-        _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
-        _TIMER.stop(e0, name + suffix, flops, nbytes + 8.0 * split * rows * n, staged)
-        return
     if split <= 1:
         e0 = _TIMER.start()
         _native.check(lib.dd_gemm(ctypes.byref(d), _stream()), what)
@@ -463,7 +419,7 @@ def _rows2d(t):
 
 def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, alpha=1.0,
          out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, ln=None, out_f32=False,
-         ln_stats=False, head_major=None, ln_direct=None, w_scale=None, ln_out=None, splitk_inkernel=0):
+         ln_stats=False, head_major=None, ln_out=None):
     """out = alpha * (cat(a, a2) @ w.T + bias + rowvec[row // rows_per_inst]) + res  (fused).
     head_major = (D, scaled_planes, scale): the result comes back as (n / D, rows, D) — one contiguous
     [rows][D] plane per head of a fused Q|K|V projection, the first `scaled_planes` planes multiplied by
@@ -475,20 +431,12 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     ln_out = (gamma, beta, eps) (n == 320 only): the epilogue ALSO writes LayerNorm(out) — returned as the
     attribute `out._ln_out` — from a tile that owns whole rows (tile 40, 80 x 320).
 
-    w_scale (fp32 [n]) with `w` a torch.float8_e4m3fn [n, k] matrix: fp8 WEIGHTS with per-output-channel scales
-    (extension, quantize_fp8()); row-panel shapes only (rowpanel_ok()).
-
-    ln_direct = (gamma, beta, eps): LayerNorm PROLOGUE of the row-panel kernels — `a` is the un-normalised
-    input, every row panel is normalised in LDS (dd_layernorm's arithmetic) before it is multiplied; K in
-    {320, 640, 1280}, n a multiple of the family's column slice (rowpanel_ok()).
-
     ln = (colsum_f32, bias_f32, eps): LayerNorm fold — `a` is the UN-normalised input, `w` the
     gamma-scaled weight; the kernel computes the row statistics itself (include/dualdiff_hip.h)."""
     lib = _native.load()
     _need_gpu(a, w, bias, a2, res, rowvec, out)
     stats_in = getattr(a, "_ln_stats", None) if ln is not None else None
     a = _rows2d(a)
-    w_obj = w                                    # the caller's (cached, long-lived) tensor: target of the prefetch hints
     w = _rows2d(w)
     rows = a.shape[0]
     k = a.shape[1] + (a2.shape[1] if a2 is not None else 0)
@@ -531,7 +479,7 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
     d.out = out.data_ptr(); d.ldc = out.stride(0)
     d.alpha = alpha; d.accumulate = int(accumulate); d.epilogue = epilogue
     d.conv = 0
-    d.dtype = _dt(a); d.tile = tile; d.split_k = split_k; d.splitk_inkernel = int(splitk_inkernel)
+    d.dtype = _dt(a); d.tile = tile; d.split_k = split_k
     if ln is not None:
         if bias is not None or a2 is not None:
             raise ValueError("gemm(ln=...) folds the bias and takes a single source")
@@ -544,23 +492,8 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
             if tuple(stats_in.shape) != (rows, k // 32, 2) or stats_in.dtype != torch.float32:
                 raise ValueError("stale LayerNorm statistics attached to the input")
             d.ln_stats_in = stats_in.data_ptr()
-    if w_scale is not None:
-        _need_gpu(w_scale)
-        if w.dtype != torch.float8_e4m3fn or w_scale.dtype != torch.float32 or w_scale.numel() != n_w:
-            raise ValueError("fp8 weights: w must be float8_e4m3fn [n, k] and w_scale fp32 [n]")
-        if a2 is not None or ln is not None or epilogue != DD_EPI_NONE or not rowpanel_ok(k, n):
-            raise ValueError("fp8 weights cover the row-panel shapes only (K in {320, 640, 1280}, plain epilogue)")
-        d.w_scale = w_scale.data_ptr()
-    elif w.dtype != a.dtype:
+    if w.dtype != a.dtype:
         raise TypeError("gemm: weight dtype %s != activation dtype %s" % (w.dtype, a.dtype))
-    if ln_direct is not None:
-        if ln is not None or a2 is not None:
-            raise ValueError("gemm(ln_direct=...) takes a single source and excludes the algebraic fold")
-        g_, b_, eps_ = ln_direct
-        _need_gpu(g_, b_)
-        if g_.dtype != a.dtype or b_.dtype != a.dtype or g_.numel() != k or b_.numel() != k:
-            raise ValueError("ln_direct gamma / beta must be %s vectors of %d entries" % (a.dtype, k))
-        d.ln_gamma, d.ln_beta, d.ln_eps = g_.data_ptr(), b_.data_ptr(), float(eps_)
     ln_second = None
     if ln_out is not None:
         g_, b_, eps_ = ln_out
@@ -579,18 +512,16 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         stats_out = torch.empty((rows, n // 32, 2), dtype=torch.float32, device=a.device)
         d.ln_stats_out = stats_out.data_ptr()
     if tile == 0 and split_k == 0:
-        d.tile, d.split_k, d.splitk_inkernel = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
+        d.tile, d.split_k, _ = _autotune(lib, d, ("g", rows, n, k, epilogue, d.dtype, a2 is not None, ln is not None)
                                       + (("f32",) if out_f32 else ()) + (("so",) if ln_stats else ())
                                       + (("si",) if stats_in is not None else ())
                                       + (("hm", head_major[0]) if head_major is not None else ())
-                                      + (("lnd",) if ln_direct is not None else ()) + (("w8",) if w_scale is not None else ())
                                       + (("res",) if res is not None else ()) + (("acc",) if accumulate else ()),
                                       (rows, n), odt, a.device, warm=(a, a2, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0 or _DBG_STAMP_WS:
         ws = workspace(need, a.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
-    _pf_hint(d, w_obj)
     if _TIMER is not None:
         _timed_gemm(lib, d, "gemm", " gemm %dx%dx%d" % (rows, n_w, k) if _TIMER.shapes else "", 2.0 * rows * n_w * k,
                     2.0 * (rows * k + n_w * k + rows * n * (1 + (1 if d.res else 0) + (1 if d.accumulate else 0))),
@@ -618,8 +549,7 @@ def thin_conv_ok(cin, cout, stride, m):
 
 
 def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res=None,
-            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, splitk_inkernel=0,
-            gn_next=None):
+            alpha=1.0, out=None, accumulate=False, epilogue=DD_EPI_NONE, tile=0, split_k=0, gn_next=None):
     """3x3 / pad 1 convolution as an implicit GEMM on an NHWC batch.
 
     gn_next = (GroupNorm module, silu, want_x): the GroupNorm that reads this conv's output next.  When the conv runs
@@ -676,19 +606,18 @@ def conv3x3(x, w, bias, m, hin, win, *, stride=1, up_size=None, rowvec=None, res
     d.conv = 1
     d.hin, d.win, d.cin, d.hv, d.wv = hin, win, cin, hv, wv
     d.hout, d.wout, d.stride = hout, wout, stride
-    d.dtype = _dt(x); d.tile = tile; d.split_k = split_k; d.splitk_inkernel = int(splitk_inkernel)
+    d.dtype = _dt(x); d.tile = tile; d.split_k = split_k
     if tile == 0 and split_k == 0:
-        d.tile, d.split_k, d.splitk_inkernel = _autotune(lib, d, ("c", m, hin, win, cin, cout, stride, hv, wv, d.dtype),
+        d.tile, d.split_k, _ = _autotune(lib, d, ("c", m, hin, win, cin, cout, stride, hv, wv, d.dtype),
                                       (rows, cout), x.dtype, x.device, warm=(x, res))
     need = lib.dd_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0 or _DBG_STAMP_WS:
         ws = workspace(need, x.device)
         d.ws = ws.data_ptr(); d.ws_bytes = ws.numel() * 4
-    _pf_hint(d, w)
     if gn_next is not None and GN_SPLITK and need > 0 and alpha == 1.0 and not accumulate and epilogue == DD_EPI_NONE:
         gmod, gsilu, want_x = gn_next
-        _, split, ink = _kname(lib, d)
-        if split > 1 and not ink and lib.dd_groupnorm_is_fused(hout * wout, cout, gmod.num_groups):
+        _, split = _kname(lib, d)
+        if split > 1 and lib.dd_groupnorm_is_fused(hout * wout, cout, gmod.num_groups):
             # partial slabs only; dd_groupnorm_splitk is reduce + epilogue + GroupNorm(+SiLU) in one launch
             y = torch.empty((rows, cout), dtype=x.dtype, device=x.device)
             d.phase = 1
@@ -741,10 +670,9 @@ def groupnorm(x, gamma, beta, m, hw, groups, eps, silu, x2=None, out=None):
     _native.check(rc, "groupnorm")
     if e0 is not None:      # HBM-bound: each element read once and written once
         th = lib.dd_groupnorm_is_fused(hw, c1 + c2, groups)
-        coop = not th and lib.dd_groupnorm_is_coop(m, hw, c1 + c2)
         _TIMER.stop(e0, "dd_gn_fused_kernel<%s, %d, 8>" % ("f16" if x.dtype == torch.float16 else "bf16", th) if th
-                    else "dd_gn_coop_kernel" if coop else "dd_gn_stats_kernel + dd_gn_apply_kernel (2 launches)",
-                    0.0, (4.0 if th or coop else 6.0) * out.numel())
+                    else "dd_gn_stats_kernel + dd_gn_apply_kernel (2 launches)",
+                    0.0, (4.0 if th else 6.0) * out.numel())
     return out
 
 
@@ -1190,6 +1118,7 @@ def box_tokens(points, classes, masks, class_tokens, null_pos, null_class, freqs
     d.pos, d.cat, d.cls_out = pos.data_ptr(), cat.data_ptr(), (cls_out.data_ptr() if cls_out is not None else None)
     d.rows, d.points_per_box, d.num_freqs, d.include_input = rows, npts, nf, int(include_input)
     d.class_token_dim, d.cls_offset, d.ld_cat = class_tokens.shape[1], int(cls_offset), cat.stride(0)
+    d.n_classes = class_tokens.shape[0]          # kept rows with a class outside the table get NaN tokens, never a stray read
     d.points_dtype, d.dtype = code, _dt(class_tokens)
     for i, f in enumerate(freqs):
         d.freqs[i] = float(f)
@@ -1225,7 +1154,7 @@ def ctx_assemble(cam, text, box, n_cam, text_per_view=False, want_txt=True):
 
 def quantize_fp8(w):
     """[n, k] weight matrix -> (float8_e4m3fn [n, k], fp32 scale [n]): symmetric per-output-channel quantisation,
-    scale = max|w_row| / 448 (the e4m3fn maximum), round-to-nearest — the layout `gemm(..., w_scale=...)` takes."""
+    scale = max|w_row| / 448 (the e4m3fn maximum), round-to-nearest (what quantize_fp8_padded() builds on for gemm8)."""
     wf = w.detach().float()
     scale = (wf.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
     q = (wf / scale[:, None]).to(torch.float8_e4m3fn).contiguous()
@@ -1316,13 +1245,6 @@ def gemm8(a8, a_scale, w8, w_scale, bias=None, *, res=None, out=None, head_major
         _TIMER.stop(e0, "dd_gemm8_kernel", 2.0 * rows * n * a8.shape[1],
                     1.0 * (rows + n) * a8.shape[1] + 2.0 * rows * n * (1 + (1 if res is not None else 0)))
     return hm_out if hm_out is not None else out
-
-
-def rowpanel_ok(k, n):
-    """Shapes the row-panel GEMM family (tiles 41 / 42, LayerNorm prologue) covers: K = C of a transformer
-    level and n a whole number of its column slices (4 waves x 5 or 2 MFMA blocks of 16)."""
-    bn = {320: 320, 640: 128, 1280: 128}.get(int(k))
-    return bn is not None and int(n) % bn == 0
 
 
 def gemm_kernel_name(rows, n, k, dtype=torch.bfloat16, conv=False, cin=0, hw=(0, 0)):

@@ -27,9 +27,13 @@ extern "C" {
 #endif
 
 /* 2 (round 4): dd_gemm_desc gained splitk_inkernel / prefetch / prefetch_bytes and dd_attn_desc kv_batch_map2 in round 3
- * without a bump; the GroupNorm workspace's first 256 B are barrier state.  A binding must check BOTH the version and the
- * descriptor sizes (dd_desc_size) before the first launch: a stale pair would read past the caller's struct. */
-#define DD_ABI_VERSION 2
+ * without a bump; the GroupNorm workspace's first 256 B are barrier state.
+ * 3 (round 5): what was measured and never dispatched is gone — dd_gemm_desc lost ln_gamma / ln_beta / w_scale (row-panel
+ * family), splitk_inkernel, prefetch / prefetch_bytes; dd_attn_desc.variant takes 0 only; the cooperative GroupNorm
+ * entry points (dd_groupnorm_is_coop / _set_coop) are removed and its workspace carries no barrier state.
+ * A binding must check BOTH the version and the descriptor sizes (dd_desc_size) before the first launch: a stale
+ * pair would read past the caller's struct. */
+#define DD_ABI_VERSION 3
 
 enum { DD_F16 = 0, DD_BF16 = 1 };
 
@@ -110,10 +114,8 @@ typedef struct dd_gemm_desc {
   int32_t dtype;       /* DD_F16 / DD_BF16 */
   int32_t tile;        /* 0 = auto, else tile-config id (see dd_gemm_num_tiles) */
   int32_t split_k;     /* 0 = auto, 1 = off, >1 = number of K slices */
-  void* ws;            /* split-K workspace (>= dd_gemm_workspace_bytes): 64 KiB of per-tile arrival
-                          counters, then the fp32 partial slabs.  The counter region must be ZERO the
-                          first time a buffer is handed in; every call leaves it zero, so one buffer
-                          serves all launches of a stream.  Nothing else may write to it. */
+  void* ws;            /* split-K workspace (>= dd_gemm_workspace_bytes): 64 KiB reserved, then the fp32
+                          partial slabs; one buffer serves all launches of a stream. */
   int64_t ws_bytes;
   /* LayerNorm fold (dense mode, K in {320, 640, 1280}, no a2, no split-K): `a` holds the
    * UN-normalised rows x; the kernel computes each row's mean / rstd over its K columns in its
@@ -146,19 +148,6 @@ typedef struct dd_gemm_desc {
   int32_t out_headmajor_d;
   int32_t hm_scaled_planes;
   float hm_scale;
-  /* Direct LayerNorm prologue (dense mode, K in {320, 640, 1280}, row-panel tiles 41 / 42 only): `a` holds the
-   * UN-normalised rows; every row panel is normalised in LDS — two-pass fp32 mean / variance over the K columns,
-   * (x - mean) * rstd * ln_gamma + ln_beta rounded to the storage type, i.e. dd_layernorm's arithmetic — before
-   * it is multiplied.  Replaces LayerNorm + Linear of norm1 -> to_q/k/v, norm2 -> to_q, norm4 -> attn4 q/k/v
-   * (networks/blocks.py:150-222) without a LayerNorm launch.  ln_gamma / ln_beta: T [k]; eps in ln_eps. */
-  const void* ln_gamma;    /* NULL = no prologue */
-  const void* ln_beta;
-  /* fp8 WEIGHTS (EXTENSION, BASELINE configs[4]; dense mode, K in {320, 640, 1280}, row-panel tiles only): `w` is
-   * [n][k] OCP e4m3fn bytes (half the weight stream), w_scale fp32 [n] the per-output-channel dequantisation
-   * scale: out[r, c] = w_scale[c] * sum_k A[r, k] * fp8(W[c, k]) (+ bias ...).  The weight fragments are
-   * converted to the activation type once, when they are loaded into registers; MFMA and accumulation are as in
-   * the 16-bit path. */
-  const float* w_scale;    /* NULL = 16-bit weights */
   /* A split-K GEMM is two launches (partial slabs, then reduce + epilogue).  phase = 0 enqueues both (normal use);
    * 1 = the partial-slab launch only, 2 = the reduce launch only — so that a profiler-less caller (bench.py's
    * HIP-event brackets) can time the two kernels separately.  Ignored when split-K is off. */
@@ -172,19 +161,6 @@ typedef struct dd_gemm_desc {
   int64_t ld_ln_out;
   const void* lno_gamma;
   const void* lno_beta;
-  /* split-K form (ignored when split-K is off): 0 = two launches (fp32 slabs, then dd_splitk_reduce_kernel adds them
-   * and runs the epilogue); 1 = ONE launch: the slabs are stored write-through (sc1), every K slice takes a ticket on
-   * the tile's arrival counter (the first 64 KiB of `ws`) and the slice that arrives last adds all slabs in slice
-   * order and runs the epilogue — bit-identical to form 0.  Tiles x 4 B must fit the counter region and the slab
-   * region must be < 4 GiB, else form 0 is used. */
-  int32_t splitk_inkernel;
-  /* WEIGHT PREFETCH HINT (optional; dense DMA tiles and the direct conv only, ignored elsewhere): `prefetch_bytes` bytes
-   * at `prefetch` — the weights of the NEXT weight-bearing launch of this stream — are READ by spare workgroups of this
-   * launch (only when its grid leaves workgroup slots empty), so that they sit in the 256 MiB memory-side cache when
-   * that launch starts (a denoising step streams 3.3 GB of weights: every launch meets its weights cold otherwise).
-   * Nothing is written; the range must stay mapped for the duration of the launch.  NULL / 0 = off. */
-  const void* prefetch;
-  int64_t prefetch_bytes;
 } dd_gemm_desc;
 
 int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream);
@@ -202,11 +178,7 @@ const char* dd_gemm_kernel_name(const dd_gemm_desc* d);
  * Replaces torch.nn.GroupNorm + SiLU inside ResnetBlock2D (eps 1e-5), the
  * Transformer2DModel input norm (eps 1e-6, no SiLU) and conv_norm_out
  * (networks/unet_2d_condition_multiview.py:519-522).
- * ws: fp32 scratch, >= dd_groupnorm_workspace_bytes(M, G), private to the stream.  Its first 256 bytes are the
- * grid-barrier state of the cooperative single-launch form (dd_gn_coop_kernel: statistics, grid barrier, apply in one
- * launch for images that do not fit the register-resident form): they must be ZERO before the first call and are not
- * to be written by anyone else; every launch leaves them ready for the next.  Word 2 is a sticky timeout flag (a
- * bounded spin instead of a hang if a block never became resident; 0 in every run of this build).
+ * ws: fp32 scratch, >= dd_groupnorm_workspace_bytes(M, G), private to the stream (first 256 bytes reserved).
  * C1 + C2 = C, C % G == 0, C1 % 8 == 0, C2 % 8 == 0.
  * ------------------------------------------------------------------------- */
 int dd_groupnorm_nhwc(const void* x1, int32_t c1, const void* x2, int32_t c2,
@@ -219,13 +191,6 @@ int64_t dd_groupnorm_workspace_bytes(int32_t m, int32_t groups);
  * dd_gn_fused_kernel with that many threads (slab in registers), 0 = dd_gn_stats_kernel + dd_gn_apply_kernel
  * (for profile matching, like dd_gemm_kernel_name). */
 int dd_groupnorm_is_fused(int32_t hw, int32_t c, int32_t groups);
-/* 1 when dd_groupnorm_nhwc takes the cooperative single launch (dd_gn_coop_kernel) for m instances of hw x c — only
- * asked when dd_groupnorm_is_fused() is 0. */
-int dd_groupnorm_is_coop(int32_t m, int32_t hw, int32_t c);
-/* The cooperative form is OFF by default (measured 2 % slower on the denoising step: blocks that spin at the grid
- * barrier hold slots other streams' kernels want); 1 turns it on for the process (also: DD_GN_COOP=1). */
-void dd_groupnorm_set_coop(int32_t on);
-
 /* GroupNorm(+SiLU) that CONSUMES the partial slabs of a split-K dd_gemm launched with phase = 1 (in place of that GEMM's
  * reduce launch): x[r, c] = T( sum_z partial[z][r][c] + bias[c] + rowvec[r / hw][c] + res[r][c] ) — exactly what the
  * reduce launch would have stored (alpha = 1, no activation, no accumulate) — then y = GroupNorm(x) as above; x itself
@@ -264,7 +229,7 @@ typedef struct dd_attn_desc {
   const int32_t* kv_batch_map;        /* device ptr [batch] or NULL */
   int32_t accumulate;                 /* 1: O += result */
   int32_t dtype;
-  int32_t variant;                    /* 0 = default (tr-read V), 1 = plain LDS reads */
+  int32_t variant;                    /* 0 (the tuning variants of rounds 1-3 are gone: anything else is DD_ERR_UNSUPPORTED) */
   /* head h of q / k / v starts at element h * {q,k,v}_head_stride of its batch (0 = head_dim: the heads
    * are column blocks of one row, the reference's layout).  A head-major projection (dd_gemm_desc.
    * out_headmajor_d) passes ld = head_dim, batch stride = l * head_dim, head stride = rows * head_dim. */
@@ -381,7 +346,9 @@ typedef struct dd_box_tokens_desc {
   void* pos; void* cat; void* cls_out;
   int32_t rows, points_per_box, num_freqs, include_input, class_token_dim, cls_offset;
   int64_t ld_cat;
-  int32_t normalize, points_dtype, dtype, reserved;
+  int32_t normalize, points_dtype, dtype;
+  int32_t n_classes;   /* rows of class_tokens: a kept box's class index is wrapped like torch indexing (-1 = last row); one still
+                          outside [0, n_classes) gets NaN tokens instead of reading out of bounds.  0 = unchecked (ABI 2 callers) */
   float freqs[16]; float xyz_min[3]; float xyz_range[3];
 } dd_box_tokens_desc;
 int dd_box_tokens(const dd_box_tokens_desc* d, dd_stream_t stream);

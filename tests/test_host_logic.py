@@ -280,6 +280,18 @@ def test_fold_lora_key_validation_and_alpha():
         with pytest.raises(exc):
             fold_lora_(net3, bad)
     assert torch.equal(net3.attn1.to_q.weight, w0)
+    # network_alphas mapping in the key forms diffusers' loaders produce: all four forms name the same pair;
+    # an entry that matches nothing is an error, not a silently wrong scale
+    for key in ("attn1.processor.to_q", "unet.attn1.processor.to_q_lora.down.weight.alpha", "attn1.to_q.alpha",
+                "unet.attn1.processor.to_q_lora.alpha"):
+        net4 = seeded_init_(Holder(), 5)
+        fold_lora_(net4, lora, 0.5, network_alphas={key: 8.0})
+        assert torch.allclose(net4.attn1.to_q.weight, w0 + 0.5 * (8.0 / 4) * up @ down, atol=1e-6), key
+        assert torch.allclose(net4.attn1.to_k.weight, net.attn1.to_k.weight), key
+    net5 = seeded_init_(Holder(), 5)
+    with pytest.raises(KeyError):
+        fold_lora_(net5, lora, 0.5, network_alphas={"unet.attn7.processor.to_q_lora.down.weight.alpha": 8.0})
+    assert torch.equal(net5.attn1.to_q.weight, w0)
 
 
 def _synthetic_full_report(n_classes=40):

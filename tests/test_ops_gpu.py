@@ -49,8 +49,8 @@ def test_gemm_identity_asymmetric(ops):
     check(y, w.float().cpu().t(), torch.float16, "gemm A=I")
 
 
-ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46, 52, 59, 60]
-DMA_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 44, 46, 52]     # 29 is GEGLU-only
+ALL_TILES = [1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 20, 23, 24, 27, 28, 44, 46, 52, 59, 60]
+DMA_TILES = [11, 12, 13, 14, 15, 16, 20, 23, 24, 27, 28, 44, 46, 52]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -62,99 +62,6 @@ def test_gemm_tiles(ops, dtype, tile, rows, n, k):
     b = rnd((n,), dtype, 3)
     y = ops.gemm(a, w, b, tile=tile)
     check(y, L.linear_ref(a, w, b), dtype, "gemm tile%d %dx%dx%d" % (tile, rows, n, k))
-
-
-RP_SHAPES = [(16800, 320, 320), (1400 * 3 + 5, 960, 320), (4200, 640, 640), (350 * 2 + 9, 1920, 640),
-             (1092, 1280, 1280), (336, 3840, 1280), (28, 1280, 1280), (12, 1280, 320)]
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [41, 42])
-@pytest.mark.parametrize("rows,n,k", RP_SHAPES)
-def test_gemm_rowpanel(ops, dtype, tile, rows, n, k):
-    """Row-panel family (weights in registers, rows streamed as full-K panels): plain, bias + residual +
-    alpha, accumulate into a strided output, head-major planes with the Q scale — ragged row counts included."""
-    if tile == 42 and k == 1280:
-        pytest.skip("32-row panels of K = 1280 do not fit LDS")
-    a = rnd((rows, k), dtype, 1)
-    w = rnd((n, k), dtype, 2, 0.05)
-    b = rnd((n,), dtype, 3)
-    res = rnd((rows, n), dtype, 4)
-    check(ops.gemm(a, w, tile=tile), L.linear_ref(a, w), dtype, "rp%d plain %dx%dx%d" % (tile, rows, n, k))
-    y = ops.gemm(a, w, b, res=res, alpha=0.5, tile=tile)
-    check(y, L.linear_ref(a, w, b, res=res, alpha=0.5), dtype, "rp%d bias+res+alpha" % tile)
-    buf = rnd((rows, n + 64), dtype, 6)
-    ref = buf.float().cpu().clone()
-    ref[:, 32:32 + n] += L.linear_ref(a, w, b)
-    ops.gemm(a, w, b, out=buf[:, 32:32 + n], accumulate=True, tile=tile)
-    check(buf, ref, dtype, "rp%d accumulate strided" % tile, 2.0)
-    hd = {320: 40, 640: 80, 1280: 160}[k]
-    if n % hd == 0:
-        planes = n // hd
-        hm = ops.gemm(a, w, tile=tile, head_major=(hd, planes // 3 if planes >= 3 else planes, 0.25))
-        full = L.linear_ref(a, w)
-        nsc = (planes // 3 if planes >= 3 else planes) * hd
-        full[:, :nsc] *= 0.25
-        want = full.reshape(rows, planes, hd).permute(1, 0, 2).contiguous()
-        check(hm, want, dtype, "rp%d head-major" % tile)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 41, 42])
-@pytest.mark.parametrize("rows,n,k", [(16800, 960, 320), (1400 + 3, 320, 320), (4200, 1920, 640), (1092, 1280, 1280),
-                                      (336, 3840, 1280)])
-def test_gemm_rowpanel_layernorm_prologue(ops, dtype, tile, rows, n, k):
-    """LayerNorm prologue of the row-panel GEMM == LayerNorm kernel followed by the GEMM (the LayerNorm output
-    rounded to the storage type in both), with a residual and as head-major Q|K|V planes."""
-    if tile == 42 and k == 1280:
-        pytest.skip("32-row panels of K = 1280 do not fit LDS")
-    x = rnd((rows, k), dtype, 1) * 3 + 1
-    g = rnd((k,), dtype, 2) + 1.0
-    be = rnd((k,), dtype, 3)
-    w = rnd((n, k), dtype, 4, 0.05)
-    xn = L.layernorm_ref(x, g, be).to(dtype)                     # the reference rounds LN's output too
-    y = ops.gemm(x, w, tile=tile, ln_direct=(g, be, 1e-5))
-    check(y, L.linear_ref(xn, w), dtype, "rp%d LN prologue %dx%dx%d" % (tile, rows, n, k), 2.0)
-    if n == k:
-        res = rnd((rows, n), dtype, 5)
-        y = ops.gemm(x, w, res=res, tile=tile, ln_direct=(g, be, 1e-5))
-        check(y, L.linear_ref(xn, w, res=res), dtype, "rp%d LN prologue + res" % tile, 2.0)
-    hd = {320: 40, 640: 80, 1280: 160}[k]
-    planes = n // hd
-    hm = ops.gemm(x, w, tile=tile, ln_direct=(g, be, 1e-5), head_major=(hd, 8, 0.3))
-    full = L.linear_ref(xn, w)
-    full[:, :8 * hd] *= 0.3
-    check(hm, full.reshape(rows, planes, hd).permute(1, 0, 2).contiguous(), dtype, "rp%d LN + head-major" % tile, 2.0)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 41, 42])
-@pytest.mark.parametrize("rows,n,k", [(1400 * 2 + 3, 960, 320), (4200, 640, 640), (1092, 3840, 1280), (336, 1280, 1280)])
-def test_gemm_rowpanel_fp8_weights(ops, dtype, tile, rows, n, k):
-    """fp8 (e4m3fn) weights with per-channel scales (extension, configs[4]): the kernel must equal the same GEMM
-    on the DEQUANTISED weights (the arithmetic is identical: fragments converted to T, T MFMA) — with bias,
-    residual, and behind the LayerNorm prologue; and quantisation itself costs the expected few percent."""
-    if tile == 42 and k == 1280:
-        pytest.skip("32-row panels of K = 1280 do not fit LDS")
-    a = rnd((rows, k), dtype, 1)
-    w = rnd((n, k), dtype, 2, 0.05)
-    b = rnd((n,), dtype, 3)
-    res = rnd((rows, n), dtype, 4)
-    w8, sc = ops.quantize_fp8(w)
-    wdq = w8.float().cpu()                                       # exactly what the kernel multiplies by
-    ref = (a.float().cpu() @ wdq.t()) * sc.cpu()[None, :]
-    y = ops.gemm(a, w8, w_scale=sc, tile=tile)
-    check(y, ref, dtype, "fp8-weight rp%d plain %dx%dx%d" % (tile, rows, n, k))
-    y = ops.gemm(a, w8, b, res=res, w_scale=sc, tile=tile)
-    check(y, ref + b.float().cpu() + res.float().cpu(), dtype, "fp8-weight rp%d bias+res" % tile)
-    g = rnd((k,), dtype, 5) + 1.0
-    be = rnd((k,), dtype, 6)
-    xn = L.layernorm_ref(a, g, be).to(dtype).float()
-    y = ops.gemm(a, w8, w_scale=sc, tile=tile, ln_direct=(g, be, 1e-5))
-    check(y, (xn @ wdq.t()) * sc.cpu()[None, :], dtype, "fp8-weight rp%d LN prologue" % tile, 2.0)
-    qerr = ((ref - L.linear_ref(a, w)).norm() / L.linear_ref(a, w).norm()).item()
-    print("fp8 weight quantisation error of the product: %.3f" % qerr)
-    assert 0.005 < qerr < 0.06
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -273,7 +180,7 @@ def test_conv3x3_dma_tiles(ops, tile, case):
         check(y, ref, dtype, "conv dma tile%d split%d %s" % (tile, split, case))
 
 
-CONV3S_TILES = [31, 33, 34, 35, 36, 37, 38]
+CONV3S_TILES = [31, 34, 35, 37]
 # (m, h, w, cin, cout): 4x7 / 7x13 / 14x25 levels, ragged instance counts (partial last tile), one
 # instance per tile, Cout not a multiple of the tile
 CONV3S_CASES = [(12, 4, 7, 1280, 1280), (5, 4, 7, 128, 192), (12, 7, 13, 640, 1280), (7, 7, 13, 192, 64),
@@ -287,7 +194,7 @@ def test_conv3x3_small_image_direct(ops, tile, case, dtype):
     """Direct small-image conv family (dd_conv3s_kernel): whole instances per workgroup, taps as LDS
     row gathers; with the ResnetBlock2D epilogue and split-K over channel chunks."""
     m, h, w_, cin, cout = case
-    if h * w_ > {31: 384, 35: 128, 36: 128, 38: 128}.get(tile, 192):
+    if h * w_ > {31: 384, 35: 128}.get(tile, 192):
         pytest.skip("image larger than the tile")
     x = rnd((m * h * w_, cin), dtype, 1)
     w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
@@ -324,9 +231,9 @@ def _ln_fold(w, b, gamma, beta, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,c,n,tile", [(700, 320, 960, 0), (16800, 320, 320, 17), (350, 640, 1920, 11),
-                                          (91, 1280, 3840, 0), (1092, 1280, 1280, 15), (37, 640, 640, 18),
-                                          (4200, 640, 640, 19), (336, 1280, 1280, 21), (129, 320, 64, 26)])
+@pytest.mark.parametrize("rows,c,n,tile", [(700, 320, 960, 0), (16800, 320, 320, 13), (350, 640, 1920, 11),
+                                          (91, 1280, 3840, 0), (1092, 1280, 1280, 15), (37, 640, 640, 15),
+                                          (4200, 640, 640, 23), (336, 1280, 1280, 24), (129, 320, 64, 13)])
 def test_gemm_layernorm_fold(ops, dtype, rows, c, n, tile):
     """LayerNorm folded into the consumer GEMM (row statistics in the kernel prologue) against
     LayerNorm -> Linear of the reference; input with a non-zero row mean and per-row scale."""
@@ -358,7 +265,7 @@ def test_gemm_layernorm_fold_geglu(ops, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,c,tile", [(16800, 320, 0), (4200, 640, 17), (1092, 1280, 15), (336, 1280, 11),
+@pytest.mark.parametrize("rows,c,tile", [(16800, 320, 0), (4200, 640, 13), (1092, 1280, 15), (336, 1280, 11),
                                          (700, 320, 26), (129, 640, 14), (37, 320, 1), (350, 640, 4)])
 def test_gemm_ln_stats_producer_consumer(ops, dtype, rows, c, tile):
     """The epilogue of a C x C projection (+ residual) leaves per-row partial sums of what it stores; the
@@ -415,7 +322,7 @@ def test_gemm_layernorm_fold_rejects(ops):
         ops.gemm(x, w, None, ln=(z, z, 1e-5), tile=1)         # register-staged family has no fold
 
 
-@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29, 44, 46])
+@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 44, 46])
 def test_gemm_geglu_dma_tiles(ops, tile):
     dtype = torch.bfloat16
     rows, c = 700, 640
@@ -540,7 +447,7 @@ ATTN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 8, 9, 11, 12, 13])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[str(c) for c in ATTN_CASES])
 def test_attention(ops, dtype, variant, case):
@@ -583,7 +490,7 @@ def test_attention_softmax_spike(ops):
     check(y, L.attention_ref(q, k, v, b, lq, lk, h, d), dtype, "attention spike", 4.0)
 
 
-@pytest.mark.parametrize("variant", [0, 5, 6, 7, 8, 11, 13])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("lk", [1, 31, 33, 100, 129, 200])
 def test_attention_ragged_tail_all_scores_negative(ops, variant, lk):
     """Keys past lk are zero rows in LDS and score exactly 0.  When every real score of a row is far
@@ -600,7 +507,7 @@ def test_attention_ragged_tail_all_scores_negative(ops, variant, lk):
     check(y, ref, dtype, "attention ragged tail lk=%d v%d" % (lk, variant), 4.0)
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_v5_fused_qkv_and_neighbours(ops, dtype, variant):
     """The buffer-load staging with strided q/k/v views of one fused projection, kv_batch_map and
@@ -654,7 +561,7 @@ def test_attention_head_major_qkv(ops, dtype, case):
 LN2 = 0.6931471805599453
 
 
-@pytest.mark.parametrize("variant", [0, 5, 7, 8, 11, 12])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("kind", ["spike", "negative", "plain"])
 @pytest.mark.parametrize("lk", [1, 33, 200, 300])
 def test_attention_prescaled_q(ops, variant, kind, lk):
@@ -680,7 +587,7 @@ def test_attention_prescaled_q(ops, variant, kind, lk):
     check(y, ref, dtype, "prescaled attention %s lk=%d v%d" % (kind, lk, variant), 4.0)
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0])
 def test_attention_v5_softmax_spike(ops, variant):
     b, lq, lk, h, d = 1, 64, 300, 8, 40
     dtype = torch.float16
@@ -859,7 +766,7 @@ def test_ors_projection_edge_cases():
 
 
 # ------------------------------------------------------------------ persistent tile walk ----
-@pytest.mark.parametrize("tile", [t for t in DMA_TILES if t not in (21, 22)] + [59])
+@pytest.mark.parametrize("tile", DMA_TILES + [59])
 def test_gemm_persistent_walk_dense(ops, tile):
     """More tiles than resident workgroups and a short K loop (the QKV / to_out shapes of the 28x50 level): the
     LDS-DMA family walks several tiles per workgroup with the ring running ahead across the tile boundary
@@ -878,7 +785,7 @@ def test_gemm_persistent_walk_dense(ops, tile):
     assert torch.equal(y, y0), "tile %d and tile 12 disagree bitwise" % tile
 
 
-@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 25, 29, 44, 46])
+@pytest.mark.parametrize("tile", [11, 12, 14, 16, 20, 24, 44, 46])
 def test_gemm_persistent_walk_geglu_headmajor(ops, tile):
     dtype = torch.bfloat16
     rows, c = 16800, 320
@@ -887,12 +794,11 @@ def test_gemm_persistent_walk_geglu_headmajor(ops, tile):
     b = rnd((8 * c,), dtype, 3)
     y = ops.gemm(a, w, b, epilogue=ops.DD_EPI_GEGLU, tile=tile)
     check(y, L.linear_ref(a, w, b, geglu=True), dtype, "persistent geglu tile%d" % tile, 2.0)
-    if tile != 29:
-        w3 = rnd((3 * c, c), dtype, 5, 0.05)
-        hm = ops.gemm(a, w3, None, head_major=(40, 8, 0.5), tile=tile)        # (24 planes, rows, 40)
-        ref = L.linear_ref(a, w3, None).reshape(rows, 24, 40).permute(1, 0, 2).clone()
-        ref[:8] *= 0.5
-        check(hm, ref, dtype, "persistent head-major tile%d" % tile, 2.0)
+    w3 = rnd((3 * c, c), dtype, 5, 0.05)
+    hm = ops.gemm(a, w3, None, head_major=(40, 8, 0.5), tile=tile)        # (24 planes, rows, 40)
+    ref = L.linear_ref(a, w3, None).reshape(rows, 24, 40).permute(1, 0, 2).clone()
+    ref[:8] *= 0.5
+    check(hm, ref, dtype, "persistent head-major tile%d" % tile, 2.0)
 
 
 # ------------------------------------------------------------------ pipelined dense family (round 5) ----
@@ -1024,92 +930,6 @@ def test_conv3x3_band_direct(ops, case, dtype):
     assert torch.equal(y1, y2)
 
 
-# ------------------------------------------------------------------ split-K reduced inside the launch ----
-# dd_gemm_desc.splitk_inkernel = 1 (round 3): write-through (sc1) slabs + arrival ticket + ordered reduction by the
-# last-arriving K slice (CDNA4 guide recipe; the 8 XCD L2s are not coherent).  The sum order is the slice order in
-# both forms, so the result must be BIT-IDENTICAL to the two-launch form.  Hazards the tests provoke on purpose:
-# stale lines (the SAME workspace is re-used by back-to-back launches with different inputs, slabs of the previous
-# launch may sit in an L1 / L2), several tiles per CU, ragged tile rows / columns, arrival counters left non-zero.
-INK_DENSE = [(1092, 1280, 1280, 13, 2), (1092, 1280, 1280, 15, 4), (336, 1280, 1280, 13, 5), (336, 1280, 6400, 17, 8),
-             (1092, 3840, 1280, 44, 2), (4200, 640, 640, 15, 2), (16800, 320, 1600, 28, 3), (77, 72, 1024, 18, 4),
-             (200, 328, 2048, 12, 16), (1092, 1280, 5120, 20, 6)]
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,n,k,tile,split", INK_DENSE, ids=lambda v: str(v))
-def test_gemm_split_k_inkernel_bitwise(ops, dtype, rows, n, k, tile, split):
-    w = rnd((n, k), dtype, 2, k ** -0.5)
-    b = rnd((n,), dtype, 3)
-    for it in range(6):                              # different inputs through the same workspace, back to back
-        a = rnd((rows, k), dtype, 10 + it)
-        res = rnd((rows, n), dtype, 20 + it)
-        y2 = ops.gemm(a, w, b, res=res, tile=tile, split_k=split, splitk_inkernel=0)
-        y1 = ops.gemm(a, w, b, res=res, tile=tile, split_k=split, splitk_inkernel=1)
-        assert torch.equal(y1, y2), "in-launch reduction differs from the two-launch form (iteration %d)" % it
-    check(y1, L.linear_ref(a, w, b, res=res), dtype, "gemm split%d in-kernel tile%d" % (split, tile))
-    name = ops._kname(ops._native.load(), _desc_for(ops, a, w, tile, split))
-    assert name[1] >= 2 and name[2], "the in-launch form was not taken: %s" % (name,)
-
-
-def _desc_for(ops, a, w, tile, split):
-    d = ops.GemmDesc()
-    d.a, d.w, d.out = a.data_ptr(), w.data_ptr(), a.data_ptr()
-    d.rows, d.n, d.k, d.k1 = a.shape[0], w.shape[0], a.shape[1], a.shape[1]
-    d.lda, d.ldc, d.alpha = a.stride(0), w.shape[0], 1.0
-    d.dtype = ops.DD_F16 if a.dtype == torch.float16 else ops.DD_BF16
-    d.tile, d.split_k, d.splitk_inkernel = tile, split, 1
-    return d
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile,case,split", [(31, (12, 4, 7, 1280, 1280), 5), (31, (12, 7, 13, 640, 1280), 2),
-                                             (33, (12, 7, 13, 1280, 1280), 4), (31, (3, 14, 25, 640, 640), 2), (37, (7, 7, 13, 192, 64), 3),
-                                             (31, (5, 4, 7, 2560, 1280), 8), (39, (3, 28, 50, 320, 320), 5),
-                                             (12, (12, 7, 13, 640, 1280), 3)], ids=lambda v: str(v))
-def test_conv_split_k_inkernel_bitwise(ops, dtype, tile, case, split):
-    """The direct small-image conv, its band form and the implicit-GEMM conv with the in-launch reduction, with the
-    ResnetBlock2D epilogue (bias + time vector + residual) run by the last-arriving slice."""
-    m, h, w_, cin, cout = case
-    w = rnd((cout, cin, 3, 3), dtype, 2, (9 * cin) ** -0.5)
-    wp = L.pack_conv_weight(w)
-    b = rnd((cout,), dtype, 3)
-    for it in range(4):
-        x = rnd((m * h * w_, cin), dtype, 30 + it)
-        temb = rnd((m, cout), dtype, 40 + it)
-        res = rnd((m * h * w_, cout), dtype, 50 + it)
-        y2 = ops.conv3x3(x, wp, b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split, splitk_inkernel=0)
-        y1 = ops.conv3x3(x, wp, b, m, h, w_, rowvec=temb, res=res, tile=tile, split_k=split, splitk_inkernel=1)
-        assert torch.equal(y1, y2), "conv in-launch reduction differs (iteration %d)" % it
-    ref = L.conv3x3_ref(x, w, b, m, h, w_) + temb.float().cpu().repeat_interleave(h * w_, 0) + res.float().cpu()
-    check(y1, ref, dtype, "conv tile%d split%d in-kernel %s" % (tile, split, case))
-
-
-def test_split_k_inkernel_under_load_and_streams(ops):
-    """Pitfall 3 of the guide's hand-off section: a test on an idle chip with cold lines can pass while the kernel
-    is stale.  Here two streams run in-launch split-K GEMMs of different shapes concurrently (each stream has its
-    own workspace), 40 launches each with fresh inputs, while a third stream streams through a 1 GiB buffer; every
-    result is compared bitwise with the two-launch form computed afterwards."""
-    dtype = torch.float16
-    shapes = [(1092, 1280, 1280, 13, 4), (336, 1280, 5120, 15, 8)]
-    ws = [rnd((n, k), dtype, 2 + i, k ** -0.5) for i, (_, n, k, _, _) in enumerate(shapes)]
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-    outs = [[], []]
-    ins = [[rnd((rows, k), dtype, 100 * i + it) for it in range(40)] for i, (rows, _, k, _, _) in enumerate(shapes)]
-    torch.cuda.synchronize()
-    for it in range(40):
-        with torch.cuda.stream(streams[2]):
-            big.add_(1)
-        for i, (rows, n, k, tile, split) in enumerate(shapes):
-            with torch.cuda.stream(streams[i]):
-                outs[i].append(ops.gemm(ins[i][it], ws[i], tile=tile, split_k=split, splitk_inkernel=1))
-    torch.cuda.synchronize()
-    for i, (rows, n, k, tile, split) in enumerate(shapes):
-        for it in range(40):
-            y2 = ops.gemm(ins[i][it], ws[i], tile=tile, split_k=split, splitk_inkernel=0)
-            assert torch.equal(outs[i][it], y2), "shape %d launch %d" % (i, it)
-
-
 # ------------------------------------------------------------------ neighbour PAIR in one attention launch ----
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("prescaled", [False, True])
@@ -1163,7 +983,7 @@ def test_attention_pair_rejects(ops):
     with pytest.raises(ValueError):
         ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map2=mp)                    # needs kv_batch_map
     with pytest.raises(RuntimeError):
-        ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map=mp, kv_batch_map2=mp, variant=7)   # default kernels only
+        ops.attention(q, q, q, 6, 64, 64, 8, 40, kv_batch_map=mp, kv_batch_map2=mp, variant=7)   # the variants are gone (ABI 3)
 
 
 # ------------------------------------------------------------------ fused cross-attention (dd_xattn320) ----
@@ -1331,74 +1151,3 @@ def test_conv_splitk_reduce_folded_into_groupnorm(ops, dtype, case, silu, want_x
             gn.run(out, m, h * w_, silu)              # the cache is consumed once and x was never written
 
 
-# ------------------------------------------------------------------ weight prefetch by spare workgroups ----
-@pytest.mark.parametrize("tile,split", [(52, 1), (14, 1), (13, 3), (59, 1)])
-def test_gemm_prefetch_hint_changes_nothing(ops, tile, split):
-    """dd_gemm_desc.prefetch: spare workgroups at the end of the grid only READ the hinted range (the next launch's
-    weights) — the result is bit-identical with and without the hint, for ranges that are not a multiple of the
-    per-workgroup share — exercised through the Python-side hint chain (ops.PREFETCH, off by default)."""
-    dtype = torch.float16
-    rows, n, k = 1092, 1280, 1280
-    a, w, b = rnd((rows, k), dtype, 1), rnd((n, k), dtype, 2, 0.03), rnd((n,), dtype, 3)
-    nxt = rnd((1288, k), dtype, 4, 0.03)                            # the "next" weights: 3.3 MB, not a multiple of the shares
-    ref = ops.gemm(a, w, b, tile=tile, split_k=split)
-    old = ops.PREFETCH
-    try:
-        ops.PREFETCH = True
-        ops._PF_LAST.clear(); ops._PF_NEXT.clear()
-        ops.gemm(a, w, b, tile=tile, split_k=split)                 # records nothing yet (no predecessor)
-        ops.gemm(a, nxt, None, tile=tile, split_k=split)            # chain: w -> nxt (both tensors stay alive)
-        y = ops.gemm(a, w, b, tile=tile, split_k=split)             # this launch carries the hint for nxt
-        hint = ops._PF_NEXT.get(w.data_ptr())
-        assert hint is not None and hint[0]() is nxt and hint[2] == nxt.numel() * 2, "no hint recorded"
-    finally:
-        ops.PREFETCH = old
-    assert torch.equal(y, ref)
-
-
-# ------------------------------------------------------------------ cooperative single-launch GroupNorm ----
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("m,hw,c1,c2,silu", [(12, 1400, 320, 0, True), (12, 1400, 320, 0, False), (7, 1400, 320, 0, True),
-                                             (4, 1400, 320, 320, True), (2, 1400, 640, 320, True), (3, 1399, 320, 0, True),
-                                             (12, 350, 2560, 0, True)])
-def test_groupnorm_cooperative_launch(ops, dtype, m, hw, c1, c2, silu, monkeypatch):
-    """dd_gn_coop_kernel (round 3): statistics + grid barrier + apply in ONE launch for the images that do not fit the
-    register-resident form (28x50 level).  Against the fp32 reference (incl. a group whose |mean| is 100 x its std),
-    bit-reproducible over repeated launches and with three streams running it at once (the barrier state is per
-    stream), and the timeout word of the workspace stays 0.  The last case (2560 channels) is not eligible and takes
-    the two-launch path.  The form is OFF by default (2 % slower on the step) and selected here per call."""
-    lib = ops._native.load()
-    lib.dd_groupnorm_set_coop(1)
-    try:
-        _coop_body(ops, dtype, m, hw, c1, c2, silu)
-    finally:
-        lib.dd_groupnorm_set_coop(0)
-
-
-def _coop_body(ops, dtype, m, hw, c1, c2, silu):
-    x = rnd((m * hw, c1), dtype, 1)
-    x[:, :10] = x[:, :10] * 0.01 + 1.0                                   # |mean| = 100 x std in group 0
-    x2 = rnd((m * hw, c2), dtype, 2) if c2 else None
-    c = c1 + c2
-    g = 1.0 + 0.1 * rnd((c,), dtype, 3)
-    b = rnd((c,), dtype, 4, 0.1)
-    y = ops.groupnorm(x, g, b, m, hw, 32, 1e-5, silu, x2=x2)
-    xf = torch.cat([x, x2], 1).float() if c2 else x.float()
-    ref = torch.nn.functional.group_norm(xf.reshape(m, hw, c).permute(0, 2, 1), 32, g.float(), b.float(), 1e-5)
-    ref = (torch.nn.functional.silu(ref) if silu else ref).permute(0, 2, 1).reshape(m * hw, c).cpu()
-    check(y, ref, dtype, "coop groupnorm m=%d hw=%d c=%d+%d" % (m, hw, c1, c2), 2.0)
-    for _ in range(3):
-        assert torch.equal(ops.groupnorm(x, g, b, m, hw, 32, 1e-5, silu, x2=x2), y)
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    torch.cuda.synchronize()
-    outs = []
-    for it in range(4):
-        for st in streams:
-            with torch.cuda.stream(st):
-                outs.append(ops.groupnorm(x, g, b, m, hw, 32, 1e-5, silu, x2=x2))
-    torch.cuda.synchronize()
-    assert all(torch.equal(o, y) for o in outs)
-    for key, ws in ops._WS.items():
-        if key[3] == "gn":
-            bar = ws.view(torch.int32)[:3].tolist()                     # count, generation, timeout flag
-            assert bar[0] == 0 and bar[2] == 0, "cooperative GroupNorm barrier state %s" % bar

@@ -158,97 +158,6 @@ def _dequantised(sd_weight, dtype):
     return (q8.float() * sc[:, None]).cpu()
 
 
-@pytest.mark.parametrize("dtype", [torch.float16])
-def test_fp8_lora_video_block_T16(gpu, dtype):
-    """EXTENSION, configs[4]: one video transformer block at 16 frames x 6 views with a folded rank-4 LoRA and fp8
-    attention-projection weights vs the CPU oracle whose projection weights are (W + up @ down) dequantised from
-    fp8 — exactly the matrices the HIP path multiplies by."""
-    from dualdiff_amd.lora import fold_lora_, lora_keys
-    from dualdiff_amd.networks.layers import Attention, enable_fp8_weights
-    from dualdiff_amd.networks.video_blocks import VideoMultiviewTransformerBlock
-    dim, n, frames = 640, 350, 16
-    ora = V.VideoMultiviewTransformerBlock(dim, 8, dim // 8, cross_attention_dim=768, neighboring_view_pair=PAIR,
-                                           n_frames=frames).eval()
-    sd = {k: C.bf16_round(v) for k, v in seeded_state_dict(ora, 51).items()}
-    blk = VideoMultiviewTransformerBlock(dim, 8, dim // 8, cross_attention_dim=768, neighboring_view_pair=PAIR,
-                                         n_frames=frames)
-    blk.load_state_dict(sd, strict=True)
-    g = torch.Generator().manual_seed(9)
-    lora = {k: torch.randn(shape, generator=g) * 0.02 for k, shape in sorted(lora_keys(blk, 4).items())}
-    blk = blk.to("cuda", dtype)
-    assert fold_lora_(blk, lora, 1.0) == 4 * sum(isinstance(m_, Attention) for m_ in blk.modules())
-    n_fp8 = enable_fp8_weights(blk)
-    assert n_fp8 == sum(isinstance(m_, Attention) for m_ in blk.modules())
-    # oracle weights := what the HIP block multiplies by: folded 16-bit weights, fp8-dequantised where the
-    # row-panel family takes over (fused Q|K|V of self-style layers, to_q of cross, to_out; K = C only)
-    qsd = {k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
-    quantised = {"attn1": ("to_q", "to_k", "to_v", "to_out.0"), "attn2": ("to_q", "to_out.0"),
-                 "attn4": ("to_q", "to_k", "to_v"), "attn_temp": ("to_q", "to_k", "to_v", "to_out.0")}
-    for name, projs in quantised.items():
-        for proj in projs:
-            key = "%s.%s.weight" % (name, proj)
-            qsd[key] = _dequantised(qsd[key], dtype)
-    ora.load_state_dict(qsd)
-    m = frames * 6
-    x = C.bf16_round(seeded_tensor((m, n, dim), 1))
-    ctx = C.bf16_round(seeded_tensor((m, 20, 768), 2))
-    with torch.no_grad():
-        ref = ora(x, encoder_hidden_states=ctx)
-        with storage_emulation(ora, dtype):
-            emul = ora(x, encoder_hidden_states=ctx)
-        y = blk.run(x.cuda().to(dtype).reshape(-1, dim), m, n, ctx.cuda().to(dtype).reshape(-1, 768), 20)
-    rec = []
-    assert report("fp8+LoRA video block C=640 T=16 vs dequantised oracle", y.reshape(m, n, dim), ref, dtype, rec, emul) <= 1.0, rec
-
-
-@pytest.mark.parametrize("dtype", [torch.float16])
-def test_fp8_lora_video_unet_16_frames(gpu, dtype):
-    """EXTENSION, configs[4] at its stated size: 16 frames x 6 views x 2 CFG halves would be 192 instances; one CFG
-    half (96 instances) of the whole video UNet with LoRA folded + fp8 projections runs here: finite, and equal (to
-    storage rounding) to the SAME HIP network carrying the dequantised weights in 16 bit — the fp8 path changes
-    where the weights are decoded, not what is computed."""
-    from dualdiff_amd.lora import fold_lora_, lora_keys
-    from dualdiff_amd.networks.layers import Attention, device_init_, enable_fp8_weights
-    from dualdiff_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiviewVideo
-    frames, m = 16, 96
-    with torch.device("cuda"):
-        net = UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames).to(dtype)
-    device_init_(net, 3)
-    g = torch.Generator(device="cuda").manual_seed(77)
-    lora = {k: torch.randn(shape, generator=g, device="cuda") * 0.02 for k, shape in sorted(lora_keys(net, 4).items())}
-    fold_lora_(net, lora, 1.0)
-    net.eval()
-    x = torch.randn((m, 4, C.H, C.W), generator=g, device="cuda").to(dtype)
-    ctx = torch.randn((m, 98, 768), generator=g, device="cuda").to(dtype)
-    with torch.no_grad():
-        enable_fp8_weights(net)
-        y8 = net(x, 481, encoder_hidden_states=ctx).sample
-        enable_fp8_weights(net, False)
-        # same network, dequantised weights in 16 bit
-        from dualdiff_amd import ops as O
-        for name, mod in net.named_modules():
-            if isinstance(mod, Attention):
-                self_style = not mod.is_cross or mod.to_k.in_features == mod.to_q.in_features
-                # attn4's out-projection is folded with the connector (16-bit GEMM), every other one is fp8
-                lins = [mod.to_q] + ([] if name.endswith("attn4") else [mod.to_out[0]]) \
-                    + ([mod.to_k, mod.to_v] if self_style else [])
-                for lin in lins:
-                    if O.rowpanel_ok(lin.in_features, lin.out_features):
-                        q8, sc = O.quantize_fp8(lin.weight.detach())
-                        lin.weight.copy_((q8.float() * sc[:, None]).to(dtype))
-                        lin._drop_cache()
-                mod._drop_cache()
-        if hasattr(net, "_invalidate"):
-            net._invalidate()
-        y16 = net(x, 481, encoder_hidden_states=ctx).sample
-    assert y8.shape == (m, 4, C.H, C.W) and torch.isfinite(y8).all() and torch.isfinite(y16).all()
-    e = rel_l2(y8, y16.float().cpu())
-    print("fp8 + LoRA video UNet, 16 frames (96 instances): fp8 path vs dequantised-16-bit path rel-L2 %.3e" % e)
-    from tests.parity_util import log_row
-    log_row("fp8+LoRA video unet T=16: fp8 path vs dequantised 16-bit path", dtype, e, 0.0, 5e-3)
-    assert e <= 5e-3
-
-
 # ------------------------------------------------------------------ bench.py --gpus N ----
 def test_bench_self_launch_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2 ...` WITHOUT a torchrun environment (the shape of the driver's command): the parent

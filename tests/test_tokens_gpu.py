@@ -68,6 +68,31 @@ def test_bbox_embedder_fused_equals_tensor_ops(gpu, dtype, pts_dtype, normalize,
     assert a.shape == (12, 20, 768) and a.dtype == dtype and torch.equal(a, b_)
 
 
+def test_box_tokens_class_index_is_bounds_checked(gpu):
+    """a kept box whose class index is the dataset's padding value (-1) or >= n_classes must not read foreign
+    memory.  -1 wraps to the last class like torch indexing; what stays out of range gives NaN class tokens (torch would
+    raise a device assert); masked-out rows ignore their class index altogether."""
+    from dualdiff_amd import ops as O
+    dtype, rows, npts, nf, ctd, ncls = torch.float16, 6, 8, 4, 768, 10
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand((rows, npts, 3), generator=g).cuda().to(dtype)
+    table = torch.randn((ncls, ctd), generator=g).cuda().to(dtype)
+    null_pos = torch.randn((npts * 3 * (1 + 2 * nf),), generator=g).cuda().to(dtype)
+    null_cls = torch.randn((ctd,), generator=g).cuda().to(dtype)
+    classes = torch.tensor([3, -1, 10, 9, 12345, -11], device="cuda")
+    masks = torch.tensor([True, True, True, True, False, False], device="cuda")
+    pos = torch.empty((rows, npts * 3 * (1 + 2 * nf)), dtype=dtype, device="cuda")
+    cat = torch.zeros((rows, 2 * ctd), dtype=dtype, device="cuda")
+    freqs = [2.0 ** i for i in range(nf)]
+    O.box_tokens(pts, classes, masks, table, null_pos, null_cls, freqs, True, pos, cat, ctd)
+    torch.cuda.synchronize()
+    got = cat[:, ctd:]
+    assert torch.equal(got[0], table[3]) and torch.equal(got[1], table[9]) and torch.equal(got[3], table[9])
+    assert torch.isnan(got[2].float()).all()                     # 10 is one past the table
+    assert torch.equal(got[4], null_cls) and torch.equal(got[5], null_cls)
+    assert torch.isfinite(pos.float()).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("box_views,text_per_view,nbox", [(6, False, 20), (1, False, 5), (6, True, 3), (6, False, 0)])
 def test_ctx_assemble(gpu, dtype, box_views, text_per_view, nbox):

@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 print("lib:", os.path.basename(os.environ.get("DD_HIP_LIB", "product")))
 for (b, lq, lk, h, d) in ((12, 1400, 1400, 8, 40), (12, 350, 350, 8, 80), (12, 91, 91, 8, 160), (12, 1400, 98, 8, 40)):

@@ -4,7 +4,7 @@ python tools/batch_scaling.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 LEVELS = ((28, 50, 320, 40), (14, 25, 640, 80), (7, 13, 1280, 160), (4, 7, 1280, 160))
 

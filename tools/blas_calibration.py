@@ -4,7 +4,7 @@ python tools/blas_calibration.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 SHAPES = ((16800, 320, 2880), (4200, 640, 5760), (1092, 1280, 11520), (336, 1280, 11520), (16800, 2560, 320),
           (4200, 5120, 640), (1092, 10240, 1280), (16800, 960, 320), (4200, 1920, 640), (1092, 3840, 1280),

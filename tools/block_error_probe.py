@@ -63,7 +63,6 @@ from dualdiff_amd.networks import blocks as B, layers as Ly     # noqa: E402
 
 
 def hip(**sw):
-    Ly.LN_DIRECT = sw.get("ln_direct", True)
     Ly.HEAD_MAJOR = sw.get("head_major", True)
     blk = B.BasicMultiviewTransformerBlock(640, 8, 80, cross_attention_dim=768, neighboring_view_pair=PAIR)
     blk.load_state_dict(sd)
@@ -80,7 +79,7 @@ def hip(**sw):
     return [rel(o.reshape(6, 350, 640), r) for o, r in zip(out, ref)]
 
 
-for name, sw in (("default", {}), ("no LN prologue", {"ln_direct": False}), ("no connector fold", {"fold": False}),
+for name, sw in (("default", {}), ("no connector fold", {"fold": False}),
                  ("row-major qkv", {"head_major": False}),
-                 ("all off", {"ln_direct": False, "fold": False, "head_major": False})):
+                 ("all off", {"fold": False, "head_major": False})):
     print("%-18s: " % name + "  ".join("%.3e" % e for e in hip(**sw)))

@@ -4,7 +4,7 @@ weight buffer (resident in the 256 MB Infinity Cache after the first pass) and r
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 
 

@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O, _native
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 cin, cout, h, w = [int(x) for x in sys.argv[1:5]]
 m = int(sys.argv[5]) if len(sys.argv) > 5 else 12
 dt = torch.float16

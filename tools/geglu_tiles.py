@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 for rows, c in ((16800, 320), (4200, 640), (1092, 1280), (336, 1280)):
     a = torch.randn(rows, c, device="cuda").to(dt); w = (torch.randn(8 * c, c, device="cuda") * c ** -0.5).to(dt)

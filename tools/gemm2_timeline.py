@@ -8,7 +8,7 @@ over 600 MB of weight buffers, as in the step) and hot (same buffer again):
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 dev = torch.device("cuda")
 O.workspace(512 << 20, dev)

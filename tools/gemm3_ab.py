@@ -5,7 +5,7 @@ launches, weights HOT (same buffer again) and COLD (rotation over ~600 MB of wei
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dt = torch.float16

@@ -3,7 +3,7 @@ LayerNorm + GEMM against rowquant(LayerNorm) + gemm8.  python tools/gemm8_bench.
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 for rows, n, k in ((16800, 960, 320), (16800, 320, 320), (4200, 1920, 640), (4200, 640, 640), (1092, 3840, 1280), (1092, 1280, 1280),
                    (336, 3840, 1280), (336, 1280, 1280), (4200, 5120, 640), (1092, 10240, 1280), (16800, 2560, 320)):

@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O, _native
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 rows, n, k = [int(x) for x in sys.argv[1:4]]
 use_res = len(sys.argv) > 4
 dt = torch.bfloat16

@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
 from dualdiff_amd.networks.txt_con_fusion import txt_con_XFormersAttn, txt_con_XFormersAttn_plus
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float16
 dev = torch.device("cuda")
 M, LQ, LK, C, H = 48, 1400, 77, 320, 8

@@ -4,7 +4,7 @@ every step re-stage the same (L1-resident) bytes: if the rate rises, the cap is 
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiff_amd import ops as O
-from tools.attn_variants import graph_time
+from tools._timing import graph_time
 dt = torch.float16
 print("lib:", os.path.basename(os.environ.get("DD_HIP_LIB", "product")))
 a = (torch.randn(8192, 8192, device="cuda")).to(dt)
