@@ -48,8 +48,12 @@ class ForwardGraphs:
 
     @staticmethod
     def flags(module):
+        """The scalar attributes of the model (the poke protocol) plus the one module-level knob of the reference that
+        changes what a forward launches: box_adapter.SPLIT_SIZE (box_adapter.py:11, chunked attention calls)."""
+        from . import box_adapter
         return tuple(sorted((k, v) for k, v in vars(module).items()
-                            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str, type(None)))))
+                            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str, type(None))))) \
+            + (("SPLIT_SIZE", box_adapter.SPLIT_SIZE),)
 
     def call(self, key, tensors, impl):
         """tensors: flat list of tensors / None; impl(list) -> flat list of output tensors."""

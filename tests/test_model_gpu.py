@@ -14,7 +14,7 @@ oracle/numerics.py; a lower bound of the reference path's rounding noise).  Requ
         e(HIP) <= max(1e-3, 1.02 * e_floor)           (fp16 and bf16 alike; tests/parity_util.py)
 i.e. 1e-3 wherever the dtype allows it, and never more than the noise the reference's own
 storage dtype produces.  Both numbers are printed for every tensor and appended to the parity CSV
-(profiles/r04_parity.csv is the tracked copy).
+(profiles/r05_parity.csv is the tracked copy).
 """
 import os
 

@@ -3,7 +3,7 @@
 TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/r04_parity.csv
+rm -f gpurun_out/r05_parity.csv
 timeout 4200 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/${TAG}_tests.log
 tail -4 gpurun_out/${TAG}_tests.log
