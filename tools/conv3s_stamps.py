@@ -7,7 +7,7 @@ from dualdiff_amd import ops as O
 dt = torch.float16
 dev = torch.device("cuda")
 O.workspace(512 << 20, dev)
-for (b, h, w, c) in ((12, 14, 25, 640), (12, 7, 13, 1280), (12, 4, 7, 1280)):
+for (b, h, w, c) in ((12, 28, 50, 320), (12, 14, 25, 640), (12, 7, 13, 1280), (12, 4, 7, 1280), (48, 28, 50, 320), (48, 14, 25, 640)):
     rows = b * h * w
     x = (torch.randn(rows, c, device=dev)).to(dt)
     wt = (torch.randn(c, 9 * c, device=dev) * (9 * c) ** -0.5).to(dt)
@@ -33,5 +33,5 @@ for (b, h, w, c) in ((12, 14, 25, 640), (12, 7, 13, 1280), (12, 4, 7, 1280)):
     print("   start spread %.1f us" % ((st[:, 6].max() - st[:, 6].min()).item() / 100.0))
     names = ("tables", "prologue issued", "first 9 steps", "loop done", "stored")
     for i, nm in enumerate(names):
-        print("   %-16s median %8.0f cyc  (p10 %8.0f, p90 %8.0f)" % (nm, t[:, i].median().item(),
-              t[:, i].quantile(0.1).item(), t[:, i].quantile(0.9).item()))
+        print("   %-16s median %8.0f cyc = %5.1f us  (p10 %8.0f, p90 %8.0f)" % (nm, t[:, i].median().item(),
+              t[:, i].median().item() / clk.median().item() / 1e3, t[:, i].quantile(0.1).item(), t[:, i].quantile(0.9).item()))
