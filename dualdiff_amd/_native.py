@@ -110,6 +110,7 @@ SIGNATURES = {
     "dd_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
                                c_int32, c_void_p]),
     "dd_attention": (c_int32, [POINTER(AttnDesc), c_void_p]),
+    "dd_attention_kernel_name": (c_char_p, [POINTER(AttnDesc)]),
     "dd_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "dd_scale": (c_int32, [c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p]),
     "dd_probe_spin": (c_int32, [c_void_p, c_uint32, c_void_p]),

@@ -442,41 +442,59 @@ int launch_attn5d(const AttnParams& p, hipStream_t s) {
   return launch_attn5<T, D, QT, KV_TILE, NBUF, WPE>(p, s);
 }
 
-template <typename T, int D>
-int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
+// Which instantiation a call takes — decided on the host from the shape alone (dd_attention_kernel_name reports it without
+// launching, so the choice is testable without a GPU): QT 16-row MFMA blocks of queries per wave, KV_TILE keys per LDS
+// tile, WPE waves per SIMD the kernel is compiled for.
+struct AttnPlan { int qt, kv_tile, wpe; bool ok; };
+
+template <int D>
+AttnPlan attn_plan(const AttnParams& p, int variant, int elem_bytes) {
+  AttnPlan pl{1, 64, 1, false};
+  if (variant != 0) return pl;                       // the tuning variants of rounds 1-3 are gone (ABI 3)
+  // K/V staging by buffer loads: 32-bit byte offsets per (batch, head) plane
+  if ((int64_t)p.lk * p.ldk * elem_bytes >= (1ll << 31) || (int64_t)p.lk * p.ldv * elem_bytes >= (1ll << 31)) return pl;
+  pl.ok = true;
   // 32 query rows per wave when the sequence is long enough to fill the chip, else 16;
   // 128-key tiles (half the barriers) for long key sequences at the small head dims
   const long blocks128 = (long)((p.lq + 127) / 128) * p.batch * p.heads;
   const bool qt2 = p.lq >= 256 && blocks128 >= 512;
-  if (variant != 0) return DD_ERR_UNSUPPORTED;       // the tuning variants of rounds 1-3 are gone (ABI 3)
-  // K/V staging by buffer loads: 32-bit byte offsets per (batch, head) plane
-  const bool v5_ok = (int64_t)p.lk * p.ldk * (int64_t)sizeof(T) < (1ll << 31) &&
-                     (int64_t)p.lk * p.ldv * (int64_t)sizeof(T) < (1ll << 31);
-  if (!v5_ok) return DD_ERR_UNSUPPORTED;
-  {
-    if constexpr (D == 40) {
-      // 32 or 48 query rows per wave (128 / 192 per workgroup).  The loop is VALU-issue-bound and only
-      // reaches that bound with the SIMDs full (4 waves at 32 rows, 3 at 48), so what decides is how
-      // evenly the workgroups fill the chip: 12 instances x 8 heads x 1400 rows is 1056 workgroups of
-      // 128 rows on 1024 slots (a second, nearly empty generation: 65 us) but 768 of 192 rows on 768
-      // slots (56 us).  Take the split with the smaller ceil(generations) / generations.
-      if (qt2) {
-        const double g2 = (double)((p.lq + 127) / 128) * p.batch * p.heads / 1024.0;
-        const double g3 = (double)((p.lq + 191) / 192) * p.batch * p.heads / 768.0;
-        auto waste = [](double g) { double c = (double)(long)g; if (c < g) c += 1.0; return c / g; };
-        if (waste(g3) < waste(g2) - 0.05)
-          // (the prescaled-q variant of the 128-key tile spills at 48 rows per wave: 64-key tiles there)
-          return p.lk >= 512 && !p.prescaled ? launch_attn5d<T, D, 3, 128, 1, 3>(p, s)
-                                             : launch_attn5d<T, D, 3, 64, 1, 3>(p, s);
-        return launch_attn5d<T, D, 2, 64, 1>(p, s);
+  if (D == 40) {
+    // 32 or 48 query rows per wave (128 / 192 per workgroup).  The loop is VALU-issue-bound and only
+    // reaches that bound with the SIMDs full (4 waves at 32 rows, 3 at 48), so what decides is how
+    // evenly the workgroups fill the chip: 12 instances x 8 heads x 1400 rows is 1056 workgroups of
+    // 128 rows on 1024 slots (a second, nearly empty generation: 65 us) but 768 of 192 rows on 768
+    // slots (56 us).  Take the split with the smaller ceil(generations) / generations.
+    if (qt2) {
+      const double g2 = (double)((p.lq + 127) / 128) * p.batch * p.heads / 1024.0;
+      const double g3 = (double)((p.lq + 191) / 192) * p.batch * p.heads / 768.0;
+      auto waste = [](double g) { double c = (double)(long)g; if (c < g) c += 1.0; return c / g; };
+      if (waste(g3) < waste(g2) - 0.05) {
+        // (the prescaled-q variant of the 128-key tile spills at 48 rows per wave: 64-key tiles there)
+        pl.qt = 3; pl.wpe = 3; pl.kv_tile = p.lk >= 512 && !p.prescaled ? 128 : 64;
+      } else {
+        pl.qt = 2;
       }
-      return launch_attn5d<T, D, 1, 64, 1>(p, s);
-    } else if constexpr (D == 80) {
-      if (qt2) return p.lk >= 512 ? launch_attn5d<T, D, 2, 128, 1>(p, s) : launch_attn5d<T, D, 2, 64, 1>(p, s);
-      return launch_attn5d<T, D, 1, 64, 1>(p, s);
-    } else {
-      return qt2 ? launch_attn5d<T, D, 2, 64, 1>(p, s) : launch_attn5d<T, D, 1, 64, 1>(p, s);
     }
+  } else if (D == 80) {
+    if (qt2) { pl.qt = 2; pl.kv_tile = p.lk >= 512 ? 128 : 64; }
+  } else {
+    if (qt2) pl.qt = 2;
+  }
+  return pl;
+}
+
+template <typename T, int D>
+int launch_attn_d(const AttnParams& p, int variant, hipStream_t s) {
+  const AttnPlan pl = attn_plan<D>(p, variant, (int)sizeof(T));
+  if (!pl.ok) return DD_ERR_UNSUPPORTED;
+  if constexpr (D == 40) {
+    if (pl.qt == 3) return pl.kv_tile == 128 ? launch_attn5d<T, D, 3, 128, 1, 3>(p, s) : launch_attn5d<T, D, 3, 64, 1, 3>(p, s);
+    return pl.qt == 2 ? launch_attn5d<T, D, 2, 64, 1>(p, s) : launch_attn5d<T, D, 1, 64, 1>(p, s);
+  } else if constexpr (D == 80) {
+    if (pl.qt == 2) return pl.kv_tile == 128 ? launch_attn5d<T, D, 2, 128, 1>(p, s) : launch_attn5d<T, D, 2, 64, 1>(p, s);
+    return launch_attn5d<T, D, 1, 64, 1>(p, s);
+  } else {
+    return pl.qt == 2 ? launch_attn5d<T, D, 2, 64, 1>(p, s) : launch_attn5d<T, D, 1, 64, 1>(p, s);
   }
 }
 
@@ -490,9 +508,8 @@ int launch_attn_t(const dd_attn_desc* d, const AttnParams& p, hipStream_t s) {
   return DD_ERR_UNSUPPORTED;
 }
 
-}  // namespace
-
-extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
+// argument checks + parameter block shared by dd_attention and dd_attention_kernel_name
+int attn_prepare(const dd_attn_desc* d, AttnParams& p) {
   if (!d || !d->q || !d->k || !d->v || !d->o) return DD_ERR_BAD_ARG;
   if (d->batch <= 0 || d->heads <= 0 || d->lq <= 0 || d->lk <= 0) return DD_ERR_BAD_ARG;
   if (d->dtype != DD_F16 && d->dtype != DD_BF16) return DD_ERR_BAD_ARG;
@@ -503,7 +520,6 @@ extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
     return DD_ERR_BAD_ARG;
   if (d->head_dim != 40 && d->head_dim != 80 && d->head_dim != 160) return DD_ERR_UNSUPPORTED;
   if ((long)d->batch * d->heads > 65535) return DD_ERR_UNSUPPORTED;
-  AttnParams p{};
   p.q = d->q; p.k = d->k; p.v = d->v; p.o = d->o;
   p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
   p.qbs = d->q_batch_stride; p.kbs = d->k_batch_stride; p.vbs = d->v_batch_stride; p.obs = d->o_batch_stride;
@@ -518,8 +534,34 @@ extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
   if ((p.qhs & 7) || (p.khs & 7) || (p.vhs & 7)) return DD_ERR_BAD_ARG;
   p.prescaled = d->q_prescaled ? 1 : 0;
   if (d->q_prescaled) p.scale_log2 = 1.0f;
+  return DD_OK;
+}
+
+thread_local char g_attn_name[160];
+
+}  // namespace
+
+extern "C" int dd_attention(const dd_attn_desc* d, dd_stream_t stream) {
+  AttnParams p{};
+  const int rc = attn_prepare(d, p);
+  if (rc != DD_OK) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dd_clear_error();
   if (d->dtype == DD_F16) return launch_attn_t<_Float16>(d, p, s);
   return launch_attn_t<__bf16>(d, p, s);
 }
+
+extern "C" const char* dd_attention_kernel_name(const dd_attn_desc* d) {
+  AttnParams p{};
+  const int rc = attn_prepare(d, p);
+  if (rc != DD_OK) return rc == DD_ERR_UNSUPPORTED ? "unsupported" : "invalid";
+  const AttnPlan pl = d->head_dim == 40 ? attn_plan<40>(p, d->variant, 2)
+                    : d->head_dim == 80 ? attn_plan<80>(p, d->variant, 2) : attn_plan<160>(p, d->variant, 2);
+  if (!pl.ok) return "unsupported";
+  const int nqb = (p.lq + 4 * pl.qt * 16 - 1) / (4 * pl.qt * 16);
+  snprintf(g_attn_name, sizeof(g_attn_name), "dd_attn5_kernel<%s, %d, %d, %d, 1, %d, %s, %s> grid=%d",
+           d->dtype == DD_F16 ? "_Float16" : "__bf16", d->head_dim, pl.qt, pl.kv_tile, pl.wpe,
+           p.prescaled ? "true" : "false", p.kv_map2 ? "true" : "false", nqb * p.batch * p.heads);
+  return g_attn_name;
+}
+

@@ -243,6 +243,10 @@ typedef struct dd_attn_desc {
 } dd_attn_desc;
 
 int dd_attention(const dd_attn_desc* d, dd_stream_t stream);
+/* Name of the kernel instantiation dd_attention would launch for `d` and its grid (query rows per wave, key tile and
+ * waves per SIMD follow from the shape): for profile matching and for testing the dispatch without a GPU, like
+ * dd_gemm_kernel_name.  "invalid" / "unsupported" mirror DD_ERR_BAD_ARG / DD_ERR_UNSUPPORTED; nothing is launched. */
+const char* dd_attention_kernel_name(const dd_attn_desc* d);
 
 /* ------------------------------------------------------------------------- *
  * Fused cross-attention of the 320-channel level (8 heads x 40, <= 128 context keys per view-instance), ONE launch:
