@@ -344,7 +344,7 @@ def _pmc_table():
     """Committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes, tools/pmc_summary.py +
     tools/refresh_profiles.sh): this round's if present, else the previous round's."""
     base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(base, name)) as f:
                 return json.load(f)["kernels"], name
