@@ -153,6 +153,17 @@ class ModelBase(nn.Module):
     # -- HIP graphs behind forward() -----------------------------------------------------------
     graph_forward = True
 
+    def _fwd_sides(self, n=3):
+        """Side streams of the PUBLIC forward() path: inside one model's own forward graph the work that does not depend
+        on the latents (cross-attention K/V bank, time embedding, condition embedding) and the ControlNet-residual adds
+        leave the serial chain.  Only forked from the stream forward() was called on (first-level forks: a forked stream
+        forking again crashes hipStreamEndCapture on ROCm 7.2), so BEVDenoiser — which runs whole models on forked
+        streams — never asks for them."""
+        sides = self.__dict__.get("_fwd_side_streams")
+        if sides is None or len(sides) < n:
+            sides = self.__dict__["_fwd_side_streams"] = [torch.cuda.Stream() for _ in range(n)]
+        return sides
+
     def _graphs(self):
         """The forward-graph cache, or None when this call must run eagerly: switched off, already inside a capture
         (BEVDenoiser records the whole step itself), a sharded model (its exchanges cannot live in a private graph), or

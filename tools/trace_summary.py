@@ -15,9 +15,12 @@ lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
 win = rows[lo:hi]
 t0, t1 = win[0][0], max(r[1] for r in win)
 def cls(n):
-    for k in ("conv3s", "gemm2_kernel", "dd_gemm_kernel", "gemm_rp_kernel", "conv3x3_thin", "splitk", "attn", "gn_stats", "gn_apply", "gn_fused", "gn_coop", "layernorm", "dd_add", "dd_scale",
+    for k in ("conv3s", "gemm3_kernel", "gemm2_kernel", "dd_gemm_kernel", "conv3x3_thin", "splitk", "attn", "gn_stats", "gn_apply", "gn_fused", "gn_coop", "layernorm", "dd_add", "dd_scale",
               "dd_silu", "conv3x3_small", "nchw", "nhwc", "timestep", "cfg_ddim"):
         if k in n:
+            if k == "gemm3_kernel":                       # pipelined dense family (round 5): <T, WM, WN, TM, TN, NSTAGE, GEGLU>
+                m = re.search(r"Lb([01])EE", n)
+                return "gemm3 " + ("geglu" if m and m.group(1) == "1" else "dense")
             if k == "gemm2_kernel":
                 m = re.search(r"Lb([01])ELb([01])E", n)
                 return "gemm2 " + ("conv" if m and m.group(1) == "1" else ("geglu" if m and m.group(2) == "1" else "dense")) if m else "gemm2"
