@@ -18,6 +18,10 @@ from .layers import HIPAttnProcessor, TimeEmbProjBank
 # HIP graphs behind the public forward() surfaces (round 5).  DD_GRAPH_FORWARD=0 switches them off process-wide,
 # `model.graph_forward = False` per model.
 GRAPH_FORWARD = os.environ.get("DD_GRAPH_FORWARD", "1") != "0"
+# Which independent sub-chains of a model's own forward graph leave the serial chain for a side stream (bit mask, A/B switch):
+# 1 UNet K/V bank GEMM, 2 UNet time embedding, 4 UNet ControlNet-residual adds, 8 ControlNet condition embedding,
+# 16 ControlNet K/V bank GEMM
+FWD_FORK = int(os.environ.get("DD_FWD_FORK", "0"))
 # data_ptr -> static output tensor of a live forward graph: a caller that hands such a tensor straight to the next
 # model (ControlNet residuals / tokens -> UNet, as pipeline_bev_controlnet.py:476-484 does with one branch) is read in
 # place instead of through a copy.  Weak: the entries die with the graph that owns the buffers.

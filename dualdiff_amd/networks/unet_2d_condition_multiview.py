@@ -281,18 +281,20 @@ class UNet2DConditionModelMultiview(ModelBase):
         """conv_in + down path + mid block — everything that does NOT depend on the ControlNet
         residuals, so a sampler can overlap it with the ControlNet branches on other streams."""
         dt = self.dtype
+        from .model_base import FWD_FORK
         main = torch.cuda.current_stream()
         sides = self._fwd_sides() if fork else None
+        f_kv, f_t, f_add = (fork and bool(FWD_FORK & 1)), (fork and bool(FWD_FORK & 2)), (fork and bool(FWD_FORK & 4))
         if self.kv_bank:
             if self.__dict__.get("_kv_bank") is None:
                 self.__dict__["_kv_bank"] = CrossKVBank(self)
-            self.__dict__["_kv_bank"].run(ctx2d, side=sides[0] if fork else None)
+            self.__dict__["_kv_bank"].run(ctx2d, side=sides[0] if f_kv else None)
         elif self.prefetch_kv:
             if self.__dict__.get("_kv_stream") is None:
                 self.__dict__["_kv_stream"] = torch.cuda.Stream()
             prefetch_cross_kv(self, ctx2d, self.__dict__["_kv_stream"])
         # 1. time (unet_2d_condition_multiview.py:404-411)
-        if fork:
+        if f_t:
             sides[1].wait_stream(main)
             with torch.cuda.stream(sides[1]):
                 emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
@@ -304,12 +306,12 @@ class UNet2DConditionModelMultiview(ModelBase):
         forward_size = any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w))
         # 2./3. conv_in + down path (:443-462)
         x = self.conv_in.run(x, m, h, w)
-        if fork:
+        if f_t:
             main.wait_stream(sides[1])
             if not torch.cuda.is_current_stream_capturing():
                 next(iter(temb.values())).record_stream(main)      # every slice views the one bank GEMM result
         skips = [(x, h, w)]
-        added = [] if fork and down_res is not None else None
+        added = [] if f_add and down_res is not None else None
 
         def add_residuals():
             """The skips produced since the last call get their ControlNet residual on the third side stream."""
@@ -331,7 +333,7 @@ class UNet2DConditionModelMultiview(ModelBase):
             add_residuals()
         # 4. mid (:476-485); its input is the un-augmented down output, the residual is added after
         x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc)
-        if self.kv_bank and fork:
+        if self.kv_bank and f_kv:
             self.__dict__["_kv_bank"].join()
         return {"x": x, "m": m, "h": h, "w": w, "skips": skips, "temb": temb, "ctx2d": ctx2d, "lc": lc,
                 "forward_size": forward_size, "added": added, "add_stream": sides[2] if added is not None else None}

@@ -467,8 +467,11 @@ class BEVControlNetModel(ModelBase):
         bboxes_3d_data = None if box_keys is None else dict(zip(box_keys, tensors[5:]))
         dt = self.dtype
         b, n_cam = sample.shape[:2]
+        from .model_base import FWD_FORK
         kv_side = None
-        if fork:
+        if fork and FWD_FORK & 16:
+            kv_side = self._fwd_sides()[1]
+        if fork and FWD_FORK & 8:
             # the condition image (6 convs over the panorama, or the ORS-3D re-layout) does not depend on the tokens: it runs
             # on a side stream beside them; the cross-attention K/V bank GEMM leaves the chain the same way
             main = torch.cuda.current_stream()
@@ -481,7 +484,6 @@ class BEVControlNetModel(ModelBase):
             if not torch.cuda.is_current_stream_capturing():
                 embedded[0].record_stream(main)
             prep = self.prepare_cond(tok, None, embedded)
-            kv_side = sides[1]
         else:
             prep = self.prepare_condition(camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
                                           use_aug_text)
