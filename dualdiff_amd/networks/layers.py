@@ -865,9 +865,7 @@ class CrossKVBank:
         self._w = None
         self._key = None
 
-    def run(self, ctx2d, side=None):
-        """side: a stream forked from the current one — the bank GEMM leaves the serial chain (the context does not depend
-        on the latents) and the first layer that needs its slice joins it (Attention.run_cross)."""
+    def run(self, ctx2d):
         mods = [m for m in self.layers if isinstance(m.processor, HIPAttnProcessor)
                 and m.to_k.in_features == ctx2d.shape[1] and m.to_k.bias is None and m.to_v.bias is None]
         if not mods:
@@ -876,25 +874,12 @@ class CrossKVBank:
         if self._w is None or self._key != key or self._w.dtype != ctx2d.dtype or self._w.device != ctx2d.device:
             self._w = torch.cat([m._fused(("to_k", "to_v")) for m in mods], dim=0).contiguous()
             self._key = key
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                allkv = O.gemm(ctx2d, self._w)
-        else:
-            allkv = O.gemm(ctx2d, self._w)
+        allkv = O.gemm(ctx2d, self._w)
         off = 0
         for m in mods:
             n2 = 2 * m.inner_dim
-            m.__dict__["_kv_prefetched"] = (ctx2d, allkv[:, off:off + n2], side)
+            m.__dict__["_kv_prefetched"] = (ctx2d, allkv[:, off:off + n2], None)
             off += n2
-        self._side = side
-
-    def join(self):
-        """Joins the side stream of the last run() (a layer may have been skipped: every fork must be joined before a
-        capture ends)."""
-        if getattr(self, "_side", None) is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._side = None
 
     def drop(self):
         for m in self.layers:

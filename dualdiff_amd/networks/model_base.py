@@ -18,10 +18,6 @@ from .layers import HIPAttnProcessor, TimeEmbProjBank
 # HIP graphs behind the public forward() surfaces (round 5).  DD_GRAPH_FORWARD=0 switches them off process-wide,
 # `model.graph_forward = False` per model.
 GRAPH_FORWARD = os.environ.get("DD_GRAPH_FORWARD", "1") != "0"
-# Which independent sub-chains of a model's own forward graph leave the serial chain for a side stream (bit mask, A/B switch):
-# 1 UNet K/V bank GEMM, 2 UNet time embedding, 4 UNet ControlNet-residual adds, 8 ControlNet condition embedding,
-# 16 ControlNet K/V bank GEMM
-FWD_FORK = int(os.environ.get("DD_FWD_FORK", "0"))
 # data_ptr -> static output tensor of a live forward graph: a caller that hands such a tensor straight to the next
 # model (ControlNet residuals / tokens -> UNet, as pipeline_bev_controlnet.py:476-484 does with one branch) is read in
 # place instead of through a copy.  Weak: the entries die with the graph that owns the buffers.
@@ -156,17 +152,6 @@ class ModelBase(nn.Module):
 
     # -- HIP graphs behind forward() -----------------------------------------------------------
     graph_forward = True
-
-    def _fwd_sides(self, n=3):
-        """Side streams of the PUBLIC forward() path: inside one model's own forward graph the work that does not depend
-        on the latents (cross-attention K/V bank, time embedding, condition embedding) and the ControlNet-residual adds
-        leave the serial chain.  Only forked from the stream forward() was called on (first-level forks: a forked stream
-        forking again crashes hipStreamEndCapture on ROCm 7.2), so BEVDenoiser — which runs whole models on forked
-        streams — never asks for them."""
-        sides = self.__dict__.get("_fwd_side_streams")
-        if sides is None or len(sides) < n:
-            sides = self.__dict__["_fwd_side_streams"] = [torch.cuda.Stream() for _ in range(n)]
-        return sides
 
     def _graphs(self):
         """The forward-graph cache, or None when this call must run eagerly: switched off, already inside a capture

@@ -232,12 +232,12 @@ class UNet2DConditionModelMultiview(ModelBase):
             out = self._forward_flat(tensors, n_down)[0]
         else:
             # the noise prediction is small (4 channels): hand the caller its own copy, not a view of graph memory
-            out = graphs.call(("unet", n_down, graphs.flags(self)), tensors, lambda ts: self._forward_flat(ts, n_down, True))[0].clone()
+            out = graphs.call(("unet", n_down, graphs.flags(self)), tensors, lambda ts: self._forward_flat(ts, n_down))[0].clone()
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)
 
-    def _forward_flat(self, tensors, n_down, fork=False):
+    def _forward_flat(self, tensors, n_down):
         """forward() on a flat tensor list [sample, t (m,) fp32, encoder_hidden_states, *down residuals, mid residual]
         (what ForwardGraphs records): NCHW in, NCHW out, residuals NCHW-shaped (channels_last strides are zero-copy)."""
         sample, t_f32, encoder_hidden_states = tensors[:3]
@@ -254,108 +254,65 @@ class UNet2DConditionModelMultiview(ModelBase):
         ctx2d = ctx.reshape(m * lc, ctx.shape[2])
         if not ctx2d.is_contiguous():
             ctx2d = ctx2d.contiguous()
-        return [self.forward_nhwc(x, m, h, w, t_f32, ctx2d, lc, down_res, mid_res, fork=fork)]
+        return [self.forward_nhwc(x, m, h, w, t_f32, ctx2d, lc, down_res, mid_res)]
 
-    def forward_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, down_res=None, mid_res=None, fork=False):
+    def forward_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, down_res=None, mid_res=None):
         """x: (m*h*w, 8) NHWC latents (4 channels zero-padded to 8); residuals: NHWC 2-D tensors in
         skip order (each entry a tensor or a tuple of tensors to be summed).  Returns eps as
-        (m, 4, h, w) NCHW.  fork (the public forward() path, where the residuals are INPUTS): the K/V bank GEMM and the
-        time embedding run on side streams beside conv_in, and every skip gets its ControlNet residual on a side stream
-        as soon as it exists instead of in 13 launches between the encoder and the decoder."""
-        state = self.encode_nhwc(x, m, h, w, t_f32, ctx2d, lc, fork=fork, down_res=down_res if fork else None)
+        (m, 4, h, w) NCHW."""
+        state = self.encode_nhwc(x, m, h, w, t_f32, ctx2d, lc)
         return self.decode_nhwc(state, down_res, mid_res)
 
-    @staticmethod
-    def _plus(t, r):
-        """t + sum(r): any number of branches (pipeline_bev_controlnet.py:421-429 sums them all), two operands per
-        3-input add."""
-        if not isinstance(r, (tuple, list)):
-            r = (r,)
-        i = 0
-        while i < len(r):
-            t = O.add(t, r[i], r[i + 1]) if i + 1 < len(r) else O.add(t, r[i])
-            i += 2
-        return t
-
-    def encode_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, fork=False, down_res=None):
+    def encode_nhwc(self, x, m, h, w, t_f32, ctx2d, lc):
         """conv_in + down path + mid block — everything that does NOT depend on the ControlNet
         residuals, so a sampler can overlap it with the ControlNet branches on other streams."""
         dt = self.dtype
-        from .model_base import FWD_FORK
-        main = torch.cuda.current_stream()
-        sides = self._fwd_sides() if fork else None
-        f_kv, f_t, f_add = (fork and bool(FWD_FORK & 1)), (fork and bool(FWD_FORK & 2)), (fork and bool(FWD_FORK & 4))
         if self.kv_bank:
             if self.__dict__.get("_kv_bank") is None:
                 self.__dict__["_kv_bank"] = CrossKVBank(self)
-            self.__dict__["_kv_bank"].run(ctx2d, side=sides[0] if f_kv else None)
+            self.__dict__["_kv_bank"].run(ctx2d)
         elif self.prefetch_kv:
             if self.__dict__.get("_kv_stream") is None:
                 self.__dict__["_kv_stream"] = torch.cuda.Stream()
             prefetch_cross_kv(self, ctx2d, self.__dict__["_kv_stream"])
         # 1. time (unet_2d_condition_multiview.py:404-411)
-        if f_t:
-            sides[1].wait_stream(main)
-            with torch.cuda.stream(sides[1]):
-                emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
-                temb = self.temb_bank.run(O.silu(emb))
-        else:
-            emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
-            temb = self.temb_bank.run(O.silu(emb))
+        emb = self.time_embedding.run(self.time_proj.run(t_f32, dt))
+        temb = self.temb_bank.run(O.silu(emb))
         # 28 % 8 != 0 -> explicit upsample sizes (:363-374, :500-501)
         forward_size = any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w))
         # 2./3. conv_in + down path (:443-462)
         x = self.conv_in.run(x, m, h, w)
-        if f_t:
-            main.wait_stream(sides[1])
-            if not torch.cuda.is_current_stream_capturing():
-                next(iter(temb.values())).record_stream(main)      # every slice views the one bank GEMM result
         skips = [(x, h, w)]
-        added = [] if f_add and down_res is not None else None
-
-        def add_residuals():
-            """The skips produced since the last call get their ControlNet residual on the third side stream."""
-            ev = torch.cuda.Event()
-            ev.record(main)
-            sides[2].wait_event(ev)
-            with torch.cuda.stream(sides[2]):
-                for (sk, sh, sw), r in zip(skips[len(added):], down_res[len(added):]):
-                    added.append((self._plus(sk, r), sh, sw))
-        if added is not None:
-            if len(down_res) != 1 + sum(len(b.resnets) + (1 if getattr(b, "downsamplers", None) else 0) for b in self.down_blocks):
-                added = None                                       # a caller's wrong count is reported by decode_nhwc
         for blk in self.down_blocks:
-            if added is not None:
-                add_residuals()
             x, h, w, s = run_down_block(blk, x, m, h, w, temb, ctx2d, lc)
             skips += s
-        if added is not None:
-            add_residuals()
         # 4. mid (:476-485); its input is the un-augmented down output, the residual is added after
         x = self.mid_block.run(x, m, h, w, temb, ctx2d, lc)
-        if self.kv_bank and f_kv:
-            self.__dict__["_kv_bank"].join()
         return {"x": x, "m": m, "h": h, "w": w, "skips": skips, "temb": temb, "ctx2d": ctx2d, "lc": lc,
-                "forward_size": forward_size, "added": added, "add_stream": sides[2] if added is not None else None}
+                "forward_size": forward_size}
 
     def decode_nhwc(self, state, down_res=None, mid_res=None):
         x, m, h, w = state["x"], state["m"], state["h"], state["w"]
         skips, temb, ctx2d, lc = list(state["skips"]), state["temb"], state["ctx2d"], state["lc"]
 
-        plus = self._plus
+        def plus(t, r):
+            """t + sum(r): any number of branches (pipeline_bev_controlnet.py:421-429 sums them all),
+            two operands per 3-input add."""
+            if not isinstance(r, (tuple, list)):
+                r = (r,)
+            if len(r) == 0:
+                return t
+            i = 0
+            while i < len(r):
+                t = O.add(t, r[i], r[i + 1]) if i + 1 < len(r) else O.add(t, r[i])
+                i += 2
+            return t
+
         # ControlNet residual add on the skips (:464-473) and on the mid output (:487-488)
         if down_res is not None:
             if len(down_res) != len(skips):
                 raise ValueError("expected %d down-block residuals, got %d" % (len(skips), len(down_res)))
-            if state.get("added") is not None:                      # done beside the encoder (forward_nhwc(fork=True))
-                main = torch.cuda.current_stream()
-                main.wait_stream(state["add_stream"])
-                skips = list(state["added"])
-                if not torch.cuda.is_current_stream_capturing():
-                    for t, _, _ in skips:
-                        t.record_stream(main)
-            else:
-                skips = [(plus(s, r), sh, sw) for (s, sh, sw), r in zip(skips, down_res)]
+            skips = [(plus(s, r), sh, sw) for (s, sh, sw), r in zip(skips, down_res)]
         if mid_res is not None:
             x = plus(x, mid_res)
         # 5. up (:491-516)

@@ -335,10 +335,10 @@ class BEVControlNetModel(ModelBase):
                     proc.num_tokens = nbox
         return out
 
-    def embed_cond(self, controlnet_cond, m):
-        """The condition image on its own (:967-972): ORS panorama through the condition embedder, or the ORS-3D volume
-        re-laid out — independent of the tokens, so forward() can run it beside them."""
+    def prepare_cond(self, tok, controlnet_cond):
+        """Condition-image half (:967-988): embed the ORS condition (or take the ORS-3D volume), SFA."""
         dt = self.dtype
+        m = tok["m"]
         if self.config.controlnet_conditioning_channel_order == "bgr":
             controlnet_cond = torch.flip(controlnet_cond, dims=[1])
         if not self.use_occ_3d:
@@ -347,13 +347,6 @@ class BEVControlNetModel(ModelBase):
             assert self.controlnet_cond_embedding is None
             cond, mc, h, w = to_nhwc(controlnet_cond.to(dt))
         assert mc == m, "condition batch %d != b*n_cam %d" % (mc, m)
-        return cond, h, w
-
-    def prepare_cond(self, tok, controlnet_cond, embedded=None):
-        """Condition-image half (:967-988): embed the ORS condition (or take the ORS-3D volume), SFA.
-        embedded: the result of embed_cond() when it was computed ahead (forward()'s side stream)."""
-        m = tok["m"]
-        cond, h, w = embedded if embedded is not None else self.embed_cond(controlnet_cond, m)
         assert not (self.use_txt_con_fusion and self.use_txt_con_fusionp)
         if self.use_txt_con_fusion or self.use_txt_con_fusionp:
             sfa = self.txt_con_fusion if self.use_txt_con_fusion else self.txt_con_fusionp
@@ -365,7 +358,7 @@ class BEVControlNetModel(ModelBase):
         out.update({"cond": cond, "h": h, "w": w})
         return out
 
-    def forward_nhwc(self, x, m, h, w, t_f32, prep, conditioning_scale=1.0, out=None, accumulate=False, kv_side=None):
+    def forward_nhwc(self, x, m, h, w, t_f32, prep, conditioning_scale=1.0, out=None, accumulate=False):
         """x: (m*h*w, 8) padded NHWC latents; returns [12 down residuals] + [mid] as NHWC 2-D tensors
         (each with its (h, w)).  With `out` (same structure) the zero convs write / accumulate in
         place — the dual-branch sum of pipeline_bev_controlnet.py:421-429 without extra passes."""
@@ -375,7 +368,7 @@ class BEVControlNetModel(ModelBase):
         if self.kv_bank:
             if self.__dict__.get("_kv_bank") is None:
                 self.__dict__["_kv_bank"] = CrossKVBank(self)
-            self.__dict__["_kv_bank"].run(ctx2d, side=kv_side)
+            self.__dict__["_kv_bank"].run(ctx2d)
         elif self.prefetch_kv:
             if self.__dict__.get("_kv_stream") is None:
                 self.__dict__["_kv_stream"] = torch.cuda.Stream()
@@ -391,8 +384,6 @@ class BEVControlNetModel(ModelBase):
         if self.__dict__.get("_kv_stream") is not None:
             drop_prefetched_kv(self, self.__dict__["_kv_stream"])
         if self.__dict__.get("_kv_bank") is not None:
-            if kv_side is not None:
-                self.__dict__["_kv_bank"].join()
             self.__dict__["_kv_bank"].drop()
         # residual scale (:1041-1055): one factor, or one per residual (guess_mode: 13 log-spaced factors);
         # either way it is the zero conv's epilogue `alpha`
@@ -452,14 +443,14 @@ class BEVControlNetModel(ModelBase):
             outs = self._forward_flat(tensors, box_keys, scale, use_aug_text)
         else:
             outs = graphs.call(("controlnet", box_keys, scale, bool(use_aug_text), graphs.flags(self)), tensors,
-                               lambda ts: self._forward_flat(ts, box_keys, scale, use_aug_text, True))
+                               lambda ts: self._forward_flat(ts, box_keys, scale, use_aug_text))
         down, mid, ctx = list(outs[:-2]), outs[-2], outs[-1]
         if not return_dict:
             return down, mid, ctx
         return BEVControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid,
                                    encoder_hidden_states_with_cam=ctx)
 
-    def _forward_flat(self, tensors, box_keys, conditioning_scale, use_aug_text, fork=False):
+    def _forward_flat(self, tensors, box_keys, conditioning_scale, use_aug_text):
         """forward() on a flat tensor list [sample (b, n, 4, h, w), t (b*n,) fp32, camera_param, encoder_hidden_states,
         controlnet_cond, *bboxes_3d_data values in key order] (what ForwardGraphs records).  Returns the 12 down
         residuals + the mid residual as logical-NCHW views of the NHWC buffers, then the tokens with the camera token."""
@@ -467,31 +458,13 @@ class BEVControlNetModel(ModelBase):
         bboxes_3d_data = None if box_keys is None else dict(zip(box_keys, tensors[5:]))
         dt = self.dtype
         b, n_cam = sample.shape[:2]
-        from .model_base import FWD_FORK
-        kv_side = None
-        if fork and FWD_FORK & 16:
-            kv_side = self._fwd_sides()[1]
-        if fork and FWD_FORK & 8:
-            # the condition image (6 convs over the panorama, or the ORS-3D re-layout) does not depend on the tokens: it runs
-            # on a side stream beside them; the cross-attention K/V bank GEMM leaves the chain the same way
-            main = torch.cuda.current_stream()
-            sides = self._fwd_sides()
-            sides[0].wait_stream(main)
-            with torch.cuda.stream(sides[0]):
-                embedded = self.embed_cond(controlnet_cond, b * n_cam)
-            tok = self.prepare_tokens(camera_param, bboxes_3d_data, encoder_hidden_states, use_aug_text)
-            main.wait_stream(sides[0])
-            if not torch.cuda.is_current_stream_capturing():
-                embedded[0].record_stream(main)
-            prep = self.prepare_cond(tok, None, embedded)
-        else:
-            prep = self.prepare_condition(camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
-                                          use_aug_text)
+        prep = self.prepare_condition(camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
+                                      use_aug_text)
         x, m, h, w = to_nhwc(sample.reshape(b * n_cam, *sample.shape[2:]).to(dt))
         if x.shape[1] != self.conv_in.cin_pad:
             x = torch.nn.functional.pad(x, (0, self.conv_in.cin_pad - x.shape[1]))
         scale = list(conditioning_scale) if isinstance(conditioning_scale, tuple) else conditioning_scale
-        outs = self.forward_nhwc(x, m, h, w, t, prep, scale, kv_side=kv_side)
+        outs = self.forward_nhwc(x, m, h, w, t, prep, scale)
         return [as_nchw_view(o, m, oh, ow) for o, oh, ow in outs] + [prep["ctx"]]
 
 
