@@ -1818,11 +1818,9 @@ constexpr TileCfg kTiles[] = {
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
     {39, 4, 2, 6, 2, -3, "conv3s band 384x64"},   // stages == -3: BAND form (images larger than the tile: 28x50 level)
-    // round 5: the same 384 x 64 tile on FOUR waves of 96 x 64 (one per SIMD): 10 fragment reads per 24 MFMAs instead of 8
-    // per 12 — the 8-wave form spends 570 LDS cycles per (chunk, tap) step beside 768 of MFMA and the two do not overlap
-    // (1365 cycles per step measured, profiles/r05_conv3s_stamps.txt)
-    {32, 4, 1, 6, 4, -1, "conv3s 384x64/4w"},
-    {45, 4, 1, 6, 4, -3, "conv3s band 384x64/4w"},
+    // (round 5: the same 384 x 64 tile on FOUR waves of 96 x 64, one per SIMD — 10 fragment reads per 24 MFMAs instead of
+    //  8 per 12 — was built, bit-identical, and 12-16 % SLOWER on every level (28x50: 40.5 vs 35.2 us): without a partner
+    //  wave the step's chain barrier -> weight reads -> MFMAs is exposed; profiles/r05_conv3s_ab.txt.  Removed.)
     {34, 2, 2, 6, 2, -1, "conv3s 192x64/w4"},
     {35, 2, 2, 4, 2, -1, "conv3s 128x64/w3"},     // 72 KB of LDS: two workgroups per CU
     {37, 2, 2, 6, 2, -1, "conv3s 192x64/g3"},     // taps in groups of three: one barrier per 72 MFMAs
@@ -2051,8 +2049,6 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
 #ifndef DD_DBG_ONLY_P        // -DDD_DBG_ONLY_P: a quick-to-compile build with the pipelined family only (reading its ISA)
     case 31: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5>(p, pl, s); break;
     case 39: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 2, 6, 2, 5, 1, true>(p, pl, s); break;
-    case 32: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 1, 6, 4, 5>(p, pl, s); break;
-    case 45: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 4, 1, 6, 4, 5, 1, true>(p, pl, s); break;
     case 34: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 4>(p, pl, s); break;
     case 35: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 3>(p, pl, s); break;
     case 37: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 6, 3>(p, pl, s); break;
@@ -2193,7 +2189,7 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
   const TileCfg& t = kTiles[pl.tile_idx];
   if (t.stages < 0) {
     const bool band = t.stages == -3;
-    const int nsw = (t.id == 31 || t.id == 32 || band) ? 5 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4));
+    const int nsw = (t.id == 31 || band) ? 5 : (t.id >= 37 ? 6 : (t.id >= 35 ? 3 : 4));
     snprintf(g_kname, sizeof(g_kname), "dd_conv3s_kernel<%s, %d, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
              d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, nsw, (t.id >= 37 && !band) ? 3 : 1,
              band ? "true" : "false", pl.split, pl.tiles_m, pl.tiles_n, t.name);
