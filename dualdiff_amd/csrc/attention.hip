@@ -22,13 +22,13 @@
 #define DD_EXP2(x) (x)
 #else
 #define DD_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 // max of 8 scores as three v_max3_f32 + one v_max_f32 (a balanced fmaxf tree compiles to seven v_max_f32: the d = 40 loop is
 // VALU-issue-bound and this is 9 instructions of ~70 per 32-key chunk)
 __device__ __forceinline__ float dd_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float dd_max8(const float (&s)[8]) {
   return fmaxf(dd_max3(dd_max3(s[0], s[1], s[2]), dd_max3(s[3], s[4], s[5]), s[6]), s[7]);
 }
-#endif
 
 namespace {
 
