@@ -1355,6 +1355,12 @@ void dd_gemm3_kernel(const GemmParams p) {
   }
   DD_STAMP(4);
   bool done = false;
+  if constexpr (!GEGLU && WAVES_M == 1 && WAVES_N == 10 && TM == 5 && TN == 2) {
+    if (p.ln_out) {                       // whole rows in this workgroup: store out AND LayerNorm(out) (store_tile_ln syncs)
+      store_tile_ln<T>(p, acc, block_m0, wave_n, lane, reinterpret_cast<float*>(smem));
+      done = true;
+    }
+  }
   if constexpr (FASTEPI) {
     if (fast) {
       const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
@@ -1814,6 +1820,7 @@ constexpr TileCfg kTiles[] = {
     {76, 2, 2, 1, 2, 104, "32x64/p4"},
     {77, 2, 2, 1, 2, 106, "32x64/p6"},
     {78, 2, 5, 5, 2, 103, "160x160/p3"},
+    {74, 1, 10, 5, 2, 103, "80x320/p3"},            // the LayerNorm-emitting tile (tile 40) on the pipelined loop
     // stages < 0: direct small-image conv (dd_conv3s_kernel); conv with stride 1 / no resize /
     // Cin % 64 == 0 / H*W <= rows of the tile only
     {31, 4, 2, 6, 2, -1, "conv3s 384x64"},
@@ -1881,10 +1888,11 @@ Plan make_plan(const dd_gemm_desc* d) {
     }
     if (kTiles[ti].stages <= 0 || kTiles[ti].stages >= 100 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }
-  if (ti >= 0 && kTiles[ti].stages >= 100 && (d->conv || d->ln_out)) { pl.unsupported = true; return pl; }   // dense only
+  if (ti >= 0 && kTiles[ti].stages >= 100 && (d->conv || (d->ln_out && kTiles[ti].id != 74))) { pl.unsupported = true; return pl; }   // dense only
   if (d->ln_out) {                                   // LayerNorm-emitting epilogue: the 80x320 tile, one column tile
-    if (d->tile > 0 && d->tile != 40) { pl.unsupported = true; return pl; }
-    for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == 40) ti = i;
+    if (d->tile > 0 && d->tile != 40 && d->tile != 74) { pl.unsupported = true; return pl; }
+    const int want = d->tile == 40 ? 40 : 74;          // default: the pipelined form (round 5)
+    for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == want) ti = i;
     if (d->n != 320 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }
   if (kTiles[ti].stages == -3) {                     // direct conv on row BANDS with a halo (images larger than the tile)
@@ -2059,6 +2067,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 76: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false>(p, pl, s); break;
     case 77: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 6, false>(p, pl, s); break;
     case 78: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
+    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 1, 10, 5, 2, 3, false>(p, pl, s); break;
 #ifndef DD_DBG_ONLY_P
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
