@@ -1891,7 +1891,9 @@ Plan make_plan(const dd_gemm_desc* d) {
   if (ti >= 0 && kTiles[ti].stages >= 100 && (d->conv || (d->ln_out && kTiles[ti].id != 74))) { pl.unsupported = true; return pl; }   // dense only
   if (d->ln_out) {                                   // LayerNorm-emitting epilogue: the 80x320 tile, one column tile
     if (d->tile > 0 && d->tile != 40 && d->tile != 74) { pl.unsupported = true; return pl; }
-    const int want = d->tile == 40 ? 40 : 74;          // default: the pipelined form (round 5)
+    // auto: the pipelined form (round 5: +0.4 % on the one-scene step) while its row tiles are one residency generation
+    // (153 KB of LDS: one workgroup per CU); beyond that the dd_gemm2 form's persistent walk wins (4 scenes: -1.6 % otherwise)
+    const int want = d->tile > 0 ? d->tile : (ceil_div(d->rows, 80) <= kNumCU ? 74 : 40);
     for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == want) ti = i;
     if (d->n != 320 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }

@@ -503,9 +503,12 @@ def gemm(a, w, bias=None, *, a2=None, res=None, rowvec=None, rows_per_inst=1, al
         ln_second = torch.empty((rows, n), dtype=a.dtype, device=a.device)
         d.ln_out, d.ld_ln_out = ln_second.data_ptr(), n
         d.lno_gamma, d.lno_beta, d.ln_eps = g_.data_ptr(), b_.data_ptr(), float(eps_)
-        # tile 74 = the 80 x 320 whole-row tile on the pipelined K loop (round 5); DD_LN_OUT_TILE=40: the dd_gemm2 form
-        tile = 40 if tile == 40 else LN_OUT_TILE
+        # the 80 x 320 whole-row tiles: 74 (pipelined K loop, round 5) / 40 (dd_gemm2, persistent walk); 0 = the library picks
+        # by the row count (DD_LN_OUT_TILE forces one for A/Bs)
+        if tile not in (40, 74):
+            tile = LN_OUT_TILE
         d.tile, d.split_k = tile, 1
+        tile = -1                                 # (not 0: no tuner lookup for this call)
     stats_out = None
     if ln_stats:
         if n % 32 or epilogue == DD_EPI_GEGLU or out_f32:
@@ -544,7 +547,7 @@ _THIN_CONV = _os.environ.get("DD_THIN_CONV", "1") != "0"       # A/B switch of d
 GN_SPLITK = _os.environ.get("DD_GN_SPLITK", "0") == "1"
 
 
-LN_OUT_TILE = int(_os.environ.get("DD_LN_OUT_TILE", "74"))
+LN_OUT_TILE = int(_os.environ.get("DD_LN_OUT_TILE", "0"))
 
 
 def thin_conv_ok(cin, cout, stride, m):
