@@ -1418,6 +1418,21 @@ void dd_gemm3_kernel(const GemmParams p) {
 // pixels (whole image rows) of one instance; its slab holds those pixels plus a halo of W + 1 pixels on either side, so
 // the activation is still staged once per 64-channel chunk (the implicit-GEMM kernels stage it once per tap).  LDS rows
 // 0..15 are the zero rows, slab pixel s sits in row 16 + s; halo pixels outside the image are out-of-range DMAs = zeros.
+// Diagnostic builds (tools/conv3s_bound.sh; never the product): which side of the (chunk, tap) step sets its length.
+//   -DDD_DBG_C3_NOMFMA   the matrix instructions are dropped (operands stay live)
+//   -DDD_DBG_C3_NOGATHER the activation fragments are gathered once, at step 0
+//   -DDD_DBG_C3_NOWREAD  the weight fragments are read once, at step 0
+//   -DDD_DBG_C3_NOBAR    no workgroup barrier in the loop
+#ifdef DD_DBG_C3_NOMFMA
+#define C3_MFMA(w, x, a) ([&]() { asm volatile("" :: "v"(w), "v"(x)); return a; }())
+#else
+#define C3_MFMA(w, x, a) dd_mfma16(w, x, a)
+#endif
+#ifdef DD_DBG_C3_NOBAR
+#define C3_BARRIER() ((void)0)
+#else
+#define C3_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW, int GRP = 1, bool BAND = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 void dd_conv3s_kernel(const GemmParams p) {
@@ -1626,6 +1641,23 @@ void dd_conv3s_kernel(const GemmParams p) {
     constexpr int par = decltype(par_c)::value;
     const bool more_c = c + 1 < nc;
     const int s = c * 9 + t;
+    // This step's DMAs (GRP == 1): W(s + NSW - 1) into the slot step s - 1 read, and at tap 0 the next chunk's pixels.
+    // Issuing an LDS-DMA costs the wave 60-185 cycles (MI355X_MICROARCH.md, "LDS-DMA piece ... issue cost"), so it is NOT
+    // done at the barrier, where it would sit in front of the late waves' MFMAs and the early waves' fragment reads with
+    // the matrix pipe idle: the late waves issue it behind their MFMAs of step s - 1, the early waves behind their reads,
+    // i.e. each under the OTHER wave's MFMAs.  Per-wave issue order (A(c+1) then W) is unchanged, so are the counted waits.
+    int dslot_ = wslot + NSW - 1;
+    if (dslot_ >= NSW) dslot_ -= NSW;
+    const int dslot = dslot_;
+    auto step_dma = [&]() __attribute__((always_inline)) {
+      if constexpr (GRP == 1) {
+        if (t == 0 && more_c) issue_a(c + 1);
+        if (s + NSW - 1 < nsteps) {
+          constexpr int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;
+          issue_w(c + ca, ta, dslot);
+        }
+      }
+    };
     if constexpr (GRP == 1) {
     // W(s) (and with it, in issue order, A(c)) must have landed.  Younger loads that may stay in
     // flight: W(s+1..s+NSW-2), and A(c+1) when it was issued after W(s) (1 <= t <= NSW-2).  The
@@ -1636,20 +1668,16 @@ void dd_conv3s_kernel(const GemmParams p) {
     } else {
       wait_vmcnt<0>();
     }
-    __builtin_amdgcn_s_barrier();
-    if (t == 0 && more_c) issue_a(c + 1);
-    if (s + NSW - 1 < nsteps) {
-      int slot = wslot + NSW - 1;
-      if (slot >= NSW) slot -= NSW;
-      constexpr int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;
-      issue_w(c + ca, ta, slot);
-    }
+    C3_BARRIER();
+#ifdef DD_DBG_C3_EARLYDMA
+    step_dma();
+#endif
     } else if constexpr (t % GRP == 0) {
       // group start: this group's taps (issued one group ago; the first two groups in the prologue) must
       // have landed; only at the very first group may the second group still be in flight
       if (s == 0 && GRP < nsteps) wait_vmcnt<GRP * WI>();
       else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();              // everyone is done with the previous group's slots
+      C3_BARRIER();              // everyone is done with the previous group's slots
       if (t == 0 && more_c) issue_a(c + 1);
       if (s >= GRP && s + GRP < nsteps) {        // next group into the slots just freed
         int slot = wslot + GRP;
@@ -1673,23 +1701,47 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par ^ 1][ks][i], xf[par ^ 1][ks][j], acc[i][j]);
+          for (int j = 0; j < TM; ++j) acc[i][j] = C3_MFMA(wf[par ^ 1][ks][i], xf[par ^ 1][ks][j], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
+#ifndef DD_DBG_C3_EARLYDMA
+      __builtin_amdgcn_sched_barrier(0);
+      step_dma();
+#endif
     }
+#ifndef DD_DBG_C3_EARLYDMA
+    if (late && s == 0) step_dma();
+#endif
+#ifdef DD_DBG_C3_NOWREAD
+    if (s == 0)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[0][ks][i] = wf[1][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + (((fchunk + 4 * ks) ^ fswz) << 3)));
+#else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
 #pragma unroll
       for (int i = 0; i < TN; ++i) wf[par][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
     }
+#endif
     if (s == 0) gather(abuf, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // first step only
+#ifdef DD_DBG_C3_NOGATHER
+    if (s == 0) gather(abuf, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    if (false) {
+#else
     // next step's activation fragments (other parity)
     if (t < 8) {
+#endif
       gather(abuf + (c & 1) * AROWS * BK, std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, par ^ 1>{});
     } else if (more_c) {
       gather(abuf + ((c + 1) & 1) * AROWS * BK, std::integral_constant<int, 0>{}, std::integral_constant<int, par ^ 1>{});
     }
     if (!late) {
+#ifndef DD_DBG_C3_EARLYDMA
+      __builtin_amdgcn_sched_barrier(0);
+      step_dma();
+#endif
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1697,7 +1749,7 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+          for (int j = 0; j < TM; ++j) acc[i][j] = C3_MFMA(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
     }
   };
@@ -1729,7 +1781,7 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+          for (int j = 0; j < TM; ++j) acc[i][j] = C3_MFMA(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
     };
     if ((nsteps - 1) & 1) drain(std::integral_constant<int, 1>{});
     else drain(std::integral_constant<int, 0>{});
@@ -2063,6 +2115,7 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 35: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 4, 2, 3>(p, pl, s); break;
     case 37: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 6, 3>(p, pl, s); break;
 #endif
+#ifndef DD_DBG_ONLY_C3       // -DDD_DBG_ONLY_C3: the direct-conv family only (tools/conv3s_bound.sh)
     case 72: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false>(p, pl, s); break;
     case 73: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
     case 75: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 3, 4, 3, GEGLU>(p, pl, s); break;
@@ -2070,7 +2123,8 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 77: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 6, false>(p, pl, s); break;
     case 78: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
     case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 1, 10, 5, 2, 3, false>(p, pl, s); break;
-#ifndef DD_DBG_ONLY_P
+#endif
+#if !defined(DD_DBG_ONLY_P) && !defined(DD_DBG_ONLY_C3)
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
     case 12: return launch_cfg2<T, 2, 2, 4, 4, 3, CONV, GEGLU>(p, pl, s);
     case 14: return launch_cfg2<T, 2, 2, 2, 4, 3, CONV, GEGLU>(p, pl, s);
