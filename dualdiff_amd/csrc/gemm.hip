@@ -45,7 +45,6 @@ struct GemmParams {
   float* stat_out;                       // [rows][n/32][2] row sum / sum of squares of the stored values, or NULL
   const float* stat_in;                  // LayerNorm fold: [rows][k/32][2] table of the `a` rows, or NULL
   int hm_d, hm_planes; float hm_scale;   // head-major output: plane width D, scaled planes, their factor
-  int no_stagger;                        // conv3s A/B switch (DD_STAGGER=0)
   int persist;                           // dd_gemm2_kernel: the grid is smaller than the tile count (see the kernel)
   uint64_t* dbg_stamps;                  // DD_DBG_STAMP builds only
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
@@ -1423,6 +1422,8 @@ void dd_gemm3_kernel(const GemmParams p) {
 //   -DDD_DBG_C3_NOGATHER the activation fragments are gathered once, at step 0
 //   -DDD_DBG_C3_NOWREAD  the weight fragments are read once, at step 0
 //   -DDD_DBG_C3_NOBAR    no workgroup barrier in the loop
+//   -DDD_DBG_C3_NOWAIT   no s_waitcnt vmcnt in the loop (operands may be stale: timing only)
+//   -DDD_DBG_C3_NODMA    no DMA issued in the loop (only the prologue's)
 #ifdef DD_DBG_C3_NOMFMA
 #define C3_MFMA(w, x, a) ([&]() { asm volatile("" :: "v"(w), "v"(x)); return a; }())
 #else
@@ -1445,13 +1446,20 @@ void dd_conv3s_kernel(const GemmParams p) {
   constexpr int BM = WAVES_M * TM * 16;
   constexpr int BN = WAVES_N * TN * 16;
   constexpr int AROWS = BAND ? BM + 88 : BM + 64;   // rows >= BM are never valid pixels -> always zeros (BAND: see above)
-  constexpr int XA = (AROWS / 8 + NW - 1) / NW;     // activation DMA pieces per wave per chunk
-  constexpr int WI = BN / 8 / NW;              // weight DMA pieces per wave per (chunk, tap) step
+  // LOADER waves: in the staggered 8-wave tiles only the early half (waves 0-3) issues LDS-DMAs — an LDS-DMA blocks the
+  // issuing wave for 60-185 cycles while the texture path is busy, and the early waves have that time: they cannot start
+  // their MFMAs before the late waves' block has left the matrix pipe.  The late waves never wait on vmcnt; the barrier
+  // behind the loaders' counted wait publishes the data.  (Round 5; all waves loading, each blocked ~220 cycles per step
+  // at the same time with the matrix pipe idle, cost 18 % of the step: profiles/r05_conv3s_segments.txt.)
+  constexpr int NL = (NW == 8 && GRP == 1) ? NW / 2 : NW;
+  constexpr int XA = (AROWS / 8 + NL - 1) / NL;     // activation DMA pieces per loader wave per chunk
+  constexpr int XPT = (XA + 3) / 4;                 // ... issued over taps 0..3, XPT per tap (GRP == 1)
+  constexpr int WI = BN / 8 / NL;              // weight DMA pieces per loader wave per (chunk, tap) step
   // NSW weight ring slots: the weights are cold (HBM, 2-3 us) while a (chunk, tap) step lasts
   // ~0.3 us, so the ring is as deep as LDS allows
-  static_assert((BAND ? AROWS % 8 == 0 : AROWS % (8 * NW) == 0) && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
+  static_assert((BAND ? AROWS % 8 == 0 : AROWS % (8 * NL) == 0) && BN % (8 * NL) == 0 && NW % 2 == 0, "tile/waves mismatch");
   static_assert(TN % 2 == 0, "TN");
-  static_assert(NSW >= 3 && NSW <= 10 && (NSW - 2) * WI + XA <= 63, "ring depth / vmcnt");
+  static_assert(NSW >= 3 && NSW <= 10 && (NSW - 2) * WI + XA <= 63 && 9 - (NSW - 1) >= 4, "ring depth / vmcnt");
 
 #ifdef DD_DBG_STAMP
   uint64_t dbg_t[6];
@@ -1495,7 +1503,6 @@ void dd_conv3s_kernel(const GemmParams p) {
   (void)ng; (void)g0;
   const int block_n0 = tile_n * BN;
 
-  const bool stagger_off = p.no_stagger != 0;
   const int nchunks = p.cin / BK;
   const int c_beg = blockIdx.z * p.chunks_per_split;
   const int nc = min(nchunks, c_beg + p.chunks_per_split) - c_beg;
@@ -1517,7 +1524,7 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
   for (int j = 0; j < XA; ++j) {
     if constexpr (BAND) {
-      const int pc = j * NW + wave;                     // 8-row piece of the slab buffer
+      const int pc = j * NL + wave;                     // 8-row piece of the slab buffer (loader waves only)
       const bool real = pc < AROWS / 8;
       const int L = (real ? pc : 0) * 8 + lrow;         // LDS row
       const int sidx = L - 16;                          // slab pixel index
@@ -1526,15 +1533,15 @@ void dd_conv3s_kernel(const GemmParams p) {
       av[j] = ok ? (uint32_t)(g0 * hw + pix) * (uint32_t)p.cin * 2u + lcb_a : DD_OOB;
       adst[j] = (real ? pc : 0) * 8;
     } else {
-      const int r = (j * NW + wave) * 8 + lrow;
+      const int r = (j * NL + wave) * 8 + lrow;
       av[j] = r < vrows ? (uint32_t)(row0 + r) * (uint32_t)p.cin * 2u + lcb_a : DD_OOB;
-      adst[j] = (j * NW + wave) * 8;
+      adst[j] = (j * NL + wave) * 8;
     }
   }
   uint32_t wv[WI];                                      // weight rows, permuted like dd_gemm2_kernel
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
-    const int R = (j * NW + wave) * 8 + lrow;
+    const int R = (j * NL + wave) * 8 + lrow;
     const int wvi = R / (TN * 16);
     const int rho = R % (TN * 16);
     const int tn = rho >> 4, r = rho & 15;
@@ -1544,17 +1551,18 @@ void dd_conv3s_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
 
-  auto issue_a = [&](int c) __attribute__((always_inline)) {           // chunk c (local index) -> abuf[c & 1]
+  auto issue_a = [&](int c, const int j0, const int j1) __attribute__((always_inline)) {   // chunk c (local index) -> abuf[c & 1], pieces [j0, j1)
     T* dst = abuf + (c & 1) * AROWS * BK;
     const uint32_t so = (uint32_t)((c_beg + c) * BK) * 2u;
 #pragma unroll
-    for (int j = 0; j < XA; ++j) bdma16(rs_a, av[j], so, dst + adst[j] * BK);
+    for (int j = 0; j < XA; ++j)
+      if (j >= j0 && j < j1) bdma16(rs_a, av[j], so, dst + adst[j] * BK);
   };
   auto issue_w = [&](int c, int t, int slot) __attribute__((always_inline)) {
     T* dst = wring + slot * BN * BK;
     const uint32_t so = (uint32_t)(t * p.cin + (c_beg + c) * BK) * 2u;
 #pragma unroll
-    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], so, dst + (j * NW + wave) * 8 * BK);
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], so, dst + (j * NL + wave) * 8 * BK);
   };
 
   f32x4 acc[TN][TM];
@@ -1568,8 +1576,9 @@ void dd_conv3s_kernel(const GemmParams p) {
   const int fchunk = lane >> 4;
 
   DD_STAMP(1);
-  if (nc > 0) {
-    issue_a(0);
+  const bool loader = wave < NL;
+  if (nc > 0 && loader) {
+    issue_a(0, 0, XA);
 #pragma unroll
     for (int s0 = 0; s0 < (GRP == 1 ? NSW - 1 : NSW); ++s0)
       if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0);
@@ -1579,6 +1588,10 @@ void dd_conv3s_kernel(const GemmParams p) {
   //  kernel in front of the first load; now they run under the 2-3 us the cold weights need to arrive)
   // ---- per-lane tap tables: LDS row of the pixel each tap reads (BM = the zero row), 2 x 16 bit
   uint32_t tab[TM][5];
+  // (entries are ABSOLUTE LDS addresses of pixel buffer 0 so that a gather is v_bfe_u32 + ds_read with the buffer as an
+  //  immediate offset; the dynamic LDS of this kernel starts at 0, and a build that moved it past the 16 bits traps)
+  const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  if (lds_base + AROWS * BK * sizeof(T) > 65536u) __builtin_trap();
   // Branch-free (bit selects on 0 / ~0 masks): written with `if`s the compiler emitted 120 exec-mask regions for
   // the 60 entries and the build took 6 200 cycles of a 69 000-cycle kernel (tools/conv3s_stamps.py).
 #pragma unroll
@@ -1609,76 +1622,106 @@ void dd_conv3s_kernel(const GemmParams p) {
         const uint32_t pad = (BAND ? 0u : (uint32_t)BM) | (lin & 15u);   // BM is a multiple of 16
         const uint32_t ok = t < 9 ? (my[t < 9 ? t / 3 : 0] & mx[t < 9 ? t % 3 : 0]) : 0u;
         uint32_t ra = (lin & ok) | (pad & ~ok);
-        // the entry is the fragment's LDS address in 16-byte units: row * 8 + swizzled chunk of k-step 0
-        // (k-step 1 is the same address with bit 2 of the chunk flipped); AROWS * 8 + 7 < 2^16
-        ra = (ra << 3) | ((uint32_t)(lane >> 4) ^ (ra & 7u));
+        // the entry is the fragment's BYTE offset inside the pixel buffer: (row * 8 + swizzled chunk of k-step 0) * 16
+        // (k-step 1 is the same address with bit 2 of the chunk flipped: ^ 64); AROWS * 128 < 2^16, so one v_bfe_u32
+        // yields the ds_read address
+        ra = (((ra << 3) | ((uint32_t)(lane >> 4) ^ (ra & 7u))) << 4) + lds_base;
         packed |= ra << (16 * h);
       }
       tab[tm][t2] = packed;
     }
   }
   int wslot = 0;                                        // ring slot of step s (scalar)
-  // Gathered activation fragments are double-buffered across steps: while the MFMAs of tap t run,
-  // the fragments of tap t+1 (same resident chunk; at t == 8 the next chunk, landed since step NSW-1)
-  // are already being read.  The buffer index is a compile-time parity, so the chunk loop is
-  // unrolled by two (9 taps per chunk is odd).
-  V8 xf[2][2][TM];
-  V8 wf[2][2][TN];                                      // weight fragments, by step parity (see STAGGER below)
-  const bool late = NW == 8 && GRP == 1 && wave >= 4 && !stagger_off;
-  auto gather = [&](const T* ab, auto tap_c, auto par_c) __attribute__((always_inline)) {
+#ifdef DD_DBG_STAMP
+  // per-wave segment clocks of the steady-state steps (s >= 9): [0] vmcnt wait, [1] barrier, [2] late block (MFMAs of
+  // step s-1 + DMA), [3] fragment reads issued AND returned (the stamp itself waits lgkmcnt(0)), [4] early block (DMA +
+  // MFMAs issued); waves 0 (early) and 4 (late) write theirs behind the phase stamps (tools/conv3s_stamps.py)
+  uint64_t seg[5] = {0, 0, 0, 0, 0};
+  uint64_t seg_prev = 0;
+#define C3_SEG(k) do { const uint64_t now_ = __builtin_readcyclecounter(); if (s >= 9) seg[k] += now_ - seg_prev; seg_prev = now_; } while (0)
+#else
+#define C3_SEG(k) do {} while (0)
+#endif
+  // One (chunk, tap) step of a wave is 24 MFMAs (~410 cycles of matrix pipe), 16 fragment reads and 1.9 LDS-DMA
+  // issues (an LDS-DMA blocks the issuing wave for 100-130 cycles).  Rounds 2-4 ran them as three blocks in series per
+  // wave and relied on the partner wave of the SIMD to fill the holes: 1235 cycles per step for 768 of MFMA, both waves
+  // issuing their DMAs at the same time with the matrix pipe idle (tools/conv3s_stamps.py segment clocks,
+  // profiles/r05_conv3s_segments.txt).  Round 5:
+  //  * the activation fragments of a wave's NEXT MFMA block are gathered INSIDE the current one, output-row block j at a
+  //    time, into the registers the four MFMAs of block j have just read (two ds_read_b128 per MFMA gap are nearly
+  //    free: MI355X_MICROARCH.md "Issued between MFMAs"; hence the j-major MFMA order) — ONE fragment buffer, not two;
+  //  * STAGGER (8-wave tiles): waves 4-7 ("late") run the MFMAs of step s-1 at the HEAD of step s, waves 0-3 ("early")
+  //    those of step s at its tail, so the two waves of a SIMD alternate on the matrix pipe behind one barrier per step
+  //    (MI355X_MICROARCH.md, "Two waves per SIMD");  early: weight fragments, DMA, MFMAs + gathers of step s+1;
+  //    late: MFMAs + gathers of step s, DMA, weight fragments — the two DMA windows are disjoint and each lies under the
+  //    other wave's MFMAs.  The role is a COMPILE-TIME parameter of the loop (two copies of it): as a run-time branch
+  //    inside every step it cost in-place accumulation and 800 spilled registers.
+  // Same arithmetic in the same order per accumulator as before -> bit-identical results.
+  V8 xf[2][TM];                                         // [k half][output-row block]
+  V8 wf[2][TN];
+  const bool late = NW == 8 && GRP == 1 && wave >= NL;
+  static_assert(AROWS * BK * sizeof(T) <= 65535, "16-bit gather addresses / immediate offset of buffer 1");
+  auto gather_j = [&](auto buf_c, auto tap_c, const int j) __attribute__((always_inline)) {
     constexpr int t = decltype(tap_c)::value;
-    constexpr int par = decltype(par_c)::value;
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      uint32_t ra = (tab[j][t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-      asm volatile("" : "+v"(ra));       // keep the 54 gather addresses out of registers: recompute per step
-      xf[par][0][j] = dd_as_v8<T>(dd_ld16(ab + (ra << 3)));
-      xf[par][1][j] = dd_as_v8<T>(dd_ld16(ab + ((ra ^ 4u) << 3)));
-    }
+    constexpr uint32_t BOFF = decltype(buf_c)::value * (AROWS * BK * sizeof(T));
+    using LP = const __attribute__((address_space(3))) u32x4*;
+    // (volatile: the extraction stays HERE — hoisted, the 54 gather addresses of a chunk cost more registers than the
+    //  kernel has, and the spill reloads wait on vmcnt(0), i.e. on the whole weight ring)
+    uint32_t a0;
+    asm volatile("v_bfe_u32 %0, %1, %2, 16" : "=v"(a0) : "v"(tab[j][t >> 1]), "n"(16 * (t & 1)));
+    xf[0][j] = dd_as_v8<T>(*(LP)(uintptr_t)(a0 + BOFF));
+    xf[1][j] = dd_as_v8<T>(*(LP)(uintptr_t)((a0 ^ 64u) + BOFF));
   };
-  auto step = [&](const int c, auto tap_c, auto par_c) __attribute__((always_inline)) {
+  auto step = [&](const int c, auto tap_c, auto buf_c, auto late_c) __attribute__((always_inline)) {
     constexpr int t = decltype(tap_c)::value;
-    constexpr int par = decltype(par_c)::value;
+    constexpr int BUF = decltype(buf_c)::value;         // = c & 1: the pixel buffer of this chunk (chunk loop unrolled by two)
+    constexpr bool LATE = decltype(late_c)::value;
     const bool more_c = c + 1 < nc;
     const int s = c * 9 + t;
-    // This step's DMAs (GRP == 1): W(s + NSW - 1) into the slot step s - 1 read, and at tap 0 the next chunk's pixels.
-    // Issuing an LDS-DMA costs the wave 60-185 cycles (MI355X_MICROARCH.md, "LDS-DMA piece ... issue cost"), so it is NOT
-    // done at the barrier, where it would sit in front of the late waves' MFMAs and the early waves' fragment reads with
-    // the matrix pipe idle: the late waves issue it behind their MFMAs of step s - 1, the early waves behind their reads,
-    // i.e. each under the OTHER wave's MFMAs.  Per-wave issue order (A(c+1) then W) is unchanged, so are the counted waits.
+    // This step's DMAs (GRP == 1, loader waves): at taps 0..3 a quarter of the next chunk's pixels, then W(s + NSW - 1)
+    // into the slot step s - 1 read.  Per-wave issue order (A pieces, then W) is what the counted waits below assume.
     int dslot_ = wslot + NSW - 1;
     if (dslot_ >= NSW) dslot_ -= NSW;
     const int dslot = dslot_;
     auto step_dma = [&]() __attribute__((always_inline)) {
+#ifndef DD_DBG_C3_NODMA
       if constexpr (GRP == 1) {
-        if (t == 0 && more_c) issue_a(c + 1);
+        if (t < 4 && more_c) issue_a(c + 1, t * XPT, (t + 1) * XPT);
         if (s + NSW - 1 < nsteps) {
           constexpr int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;
           issue_w(c + ca, ta, dslot);
         }
       }
+#endif
     };
     if constexpr (GRP == 1) {
-    // W(s) (and with it, in issue order, A(c)) must have landed.  Younger loads that may stay in
-    // flight: W(s+1..s+NSW-2), and A(c+1) when it was issued after W(s) (1 <= t <= NSW-2).  The
-    // last NSW-2 steps simply drain.
-    if (s + NSW - 2 < nsteps) {
-      if (t >= 1 && t <= NSW - 2 && more_c) wait_vmcnt<(NSW - 2) * WI + XA>();
-      else wait_vmcnt<(NSW - 2) * WI>();
-    } else {
-      wait_vmcnt<0>();
+    // W(s) (and with it, in issue order, everything older) must have landed.  Younger loads that may stay in flight:
+    // W(s+1..s+NSW-2) and the pixel pieces issued in the NSW-2 steps before this one (taps 0..3 of THIS chunk only:
+    // the previous chunk's last taps issue none).  The last NSW-2 steps simply drain.  A(c+1) is complete at step
+    // (c, 8), whose MFMA block gathers from it: its last piece went out at tap 3 <= 8 - (NSW - 1).
+#ifndef DD_DBG_C3_NOWAIT
+    if constexpr (!LATE) {
+      constexpr int ta0 = t - (NSW - 2) > 0 ? t - (NSW - 2) : 0, ta1 = t - 1 < 3 ? t - 1 : 3;      // taps [ta0, ta1]
+      constexpr int j0 = ta0 * XPT < XA ? ta0 * XPT : XA, j1 = (ta1 + 1) * XPT < XA ? (ta1 + 1) * XPT : XA;
+      constexpr int NA = ta1 >= ta0 && j1 > j0 ? j1 - j0 : 0;
+      if (s + NSW - 2 < nsteps) {
+        if (NA > 0 && more_c) wait_vmcnt<(NSW - 2) * WI + NA>();
+        else wait_vmcnt<(NSW - 2) * WI>();
+      } else {
+        wait_vmcnt<0>();
+      }
     }
-    C3_BARRIER();
-#ifdef DD_DBG_C3_EARLYDMA
-    step_dma();
 #endif
+    C3_SEG(0);
+    C3_BARRIER();
+    C3_SEG(1);
     } else if constexpr (t % GRP == 0) {
       // group start: this group's taps (issued one group ago; the first two groups in the prologue) must
       // have landed; only at the very first group may the second group still be in flight
       if (s == 0 && GRP < nsteps) wait_vmcnt<GRP * WI>();
       else wait_vmcnt<0>();
       C3_BARRIER();              // everyone is done with the previous group's slots
-      if (t == 0 && more_c) issue_a(c + 1);
+      if (t == 0 && more_c) issue_a(c + 1, 0, XA);
       if (s >= GRP && s + GRP < nsteps) {        // next group into the slots just freed
         int slot = wslot + GRP;
         if (slot >= NSW) slot -= NSW;
@@ -1689,102 +1732,106 @@ void dd_conv3s_kernel(const GemmParams p) {
     }
     const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
     if (++wslot == NSW) wslot = 0;
-    // STAGGER (8-wave tiles): the two waves of a SIMD run the same program behind one barrier per step, so
-    // without help they read LDS together and then contend for the matrix pipe together.  Waves 4-7 execute
-    // the MFMAs of step s-1 (operands already in registers) BEFORE the reads of step s, i.e. half a step out
-    // of phase with waves 0-3: one wave's MFMAs run beside the other's LDS traffic.  Same arithmetic, same
-    // order per accumulator -> bit-identical results (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-    if (late && s > 0) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = C3_MFMA(wf[par ^ 1][ks][i], xf[par ^ 1][ks][j], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-#ifndef DD_DBG_C3_EARLYDMA
-      __builtin_amdgcn_sched_barrier(0);
-      step_dma();
-#endif
-    }
-#ifndef DD_DBG_C3_EARLYDMA
-    if (late && s == 0) step_dma();
-#endif
+    auto wread = [&]() __attribute__((always_inline)) {
 #ifdef DD_DBG_C3_NOWREAD
-    if (s == 0)
+      if (s == 0)
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
+      }
+    };
+    auto mfma_j = [&](const int j) __attribute__((always_inline)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[0][ks][i] = wf[1][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + (((fchunk + 4 * ks) ^ fswz) << 3)));
-#else
+        for (int i = 0; i < TN; ++i) acc[i][j] = C3_MFMA(wf[ks][i], xf[ks][j], acc[i][j]);
+    };
+    if constexpr (LATE) {
+      // head: the MFMAs of step s-1; block j's registers are refilled with THIS step's fragments as soon as it is done
+      if (s > 0) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
+        for (int j = 0; j < TM; ++j) {
+          mfma_j(j);
+#ifndef DD_DBG_C3_NOGATHER
+          gather_j(buf_c, tap_c, j);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      } else {
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[par][ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK + cofs));
-    }
-#endif
-    if (s == 0) gather(abuf, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});   // first step only
-#ifdef DD_DBG_C3_NOGATHER
-    if (s == 0) gather(abuf, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-    if (false) {
-#else
-    // next step's activation fragments (other parity)
-    if (t < 8) {
-#endif
-      gather(abuf + (c & 1) * AROWS * BK, std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, par ^ 1>{});
-    } else if (more_c) {
-      gather(abuf + ((c + 1) & 1) * AROWS * BK, std::integral_constant<int, 0>{}, std::integral_constant<int, par ^ 1>{});
-    }
-    if (!late) {
-#ifndef DD_DBG_C3_EARLYDMA
+        for (int j = 0; j < TM; ++j) gather_j(buf_c, tap_c, j);
+      }
+      C3_SEG(2);
+      C3_SEG(3);
+      wread();
+      // the weight slot and the pixel buffer these reads touch are refilled by the loader waves right after the next barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      C3_SEG(2);
+      wread();
+      if (s == 0) {                                   // first step only: nothing was gathered under a previous block
+#pragma unroll
+        for (int j = 0; j < TM; ++j) gather_j(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, j);
+      }
       __builtin_amdgcn_sched_barrier(0);
       step_dma();
-#endif
+      C3_SEG(3);
       __builtin_amdgcn_sched_barrier(0);
+      // the MFMAs of step s; block j's registers are refilled with the fragments of step s+1 (same resident chunk; at
+      // t == 8 the next chunk, landed since step NSW-1)
+      const bool have_next = t < 8 || more_c;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = C3_MFMA(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
+      for (int j = 0; j < TM; ++j) {
+        mfma_j(j);
+#ifndef DD_DBG_C3_NOGATHER
+        if (have_next) gather_j(std::integral_constant<int, (t < 8 ? BUF : BUF ^ 1)>{}, std::integral_constant<int, (t + 1) % 9>{}, j);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
       __builtin_amdgcn_s_setprio(0);
     }
+    C3_SEG(4);
   };
-  auto chunk = [&](const int c, auto par0) __attribute__((always_inline)) {
-    constexpr int p0 = decltype(par0)::value;
-    step(c, std::integral_constant<int, 0>{}, std::integral_constant<int, p0>{});
-    step(c, std::integral_constant<int, 1>{}, std::integral_constant<int, p0 ^ 1>{});
-    step(c, std::integral_constant<int, 2>{}, std::integral_constant<int, p0>{});
-    step(c, std::integral_constant<int, 3>{}, std::integral_constant<int, p0 ^ 1>{});
-    step(c, std::integral_constant<int, 4>{}, std::integral_constant<int, p0>{});
-    step(c, std::integral_constant<int, 5>{}, std::integral_constant<int, p0 ^ 1>{});
-    step(c, std::integral_constant<int, 6>{}, std::integral_constant<int, p0>{});
-    step(c, std::integral_constant<int, 7>{}, std::integral_constant<int, p0 ^ 1>{});
-    step(c, std::integral_constant<int, 8>{}, std::integral_constant<int, p0>{});
+  auto chunk = [&](const int c, auto buf_c, auto late_c) __attribute__((always_inline)) {
+    step(c, std::integral_constant<int, 0>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 1>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 2>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 3>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 4>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 5>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 6>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 7>{}, buf_c, late_c);
+    step(c, std::integral_constant<int, 8>{}, buf_c, late_c);
   };
-  for (int c = 0; c < nc; c += 2) {
-    chunk(c, std::integral_constant<int, 0>{});            // even chunk: tap t uses parity t & 1
+  auto main_loop = [&](auto late_c) __attribute__((always_inline)) {
+    for (int c = 0; c < nc; c += 2) {
+      chunk(c, std::integral_constant<int, 0>{}, late_c);
 #ifdef DD_DBG_STAMP
-    if (c == 0) DD_STAMP(3);                               // after the first 9 steps
+      if (c == 0) DD_STAMP(3);                                       // after the first 9 steps
 #endif
-    if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{});   // odd chunk: parity (t + 1) & 1
+      if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{}, late_c);
+    }
+  };
+  if constexpr (NW == 8 && GRP == 1) {
+    if (late) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+  } else {
+    main_loop(std::false_type{});
   }
   DD_STAMP(4);
   if (late && nsteps > 0) {                               // staggered waves: the last step's MFMAs are still due
-    auto drain = [&](auto par_c) __attribute__((always_inline)) {
-      constexpr int par = decltype(par_c)::value;
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = C3_MFMA(wf[par][ks][i], xf[par][ks][j], acc[i][j]);
-    };
-    if ((nsteps - 1) & 1) drain(std::integral_constant<int, 1>{});
-    else drain(std::integral_constant<int, 0>{});
+        for (int i = 0; i < TN; ++i) acc[i][j] = C3_MFMA(wf[ks][i], xf[ks][j], acc[i][j]);
   }
   // rows past the tile's instances are padding
   store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows));
@@ -1795,6 +1842,13 @@ void dd_conv3s_kernel(const GemmParams p) {
     for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
     o[6] = dbg_r0;
     o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+  if ((wave == 0 || wave == 4) && lane == 0 && p.dbg_stamps) {
+    uint64_t* o = p.dbg_stamps + 65536 + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = seg[i];
+    o[5] = nsteps > 9 ? nsteps - 9 : 0;
+    o[6] = wave;
+    o[7] = 1;
   }
 #endif
 }
@@ -2302,8 +2356,6 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.hout = d->hout; p.wout = d->wout; p.stride = d->stride;
   p.upsample = d->conv && (d->hv != d->hin || d->wv != d->win);
   {
-    static const bool nostag = getenv("DD_STAGGER") && atoi(getenv("DD_STAGGER")) == 0;      // A/B switch
-    p.no_stagger = nostag ? 1 : 0;
     static const bool rowmajor = getenv("DD_CONV3S_ROWMAJOR") && atoi(getenv("DD_CONV3S_ROWMAJOR")) == 1;
     if (kTiles[pl.tile_idx].stages == -1 && rowmajor) p.upsample = 1;         // conv3s never resizes: flag reused
   }

@@ -21,7 +21,10 @@ for (b, h, w, c) in ((12, 28, 50, 320), (12, 14, 25, 640), (12, 7, 13, 1280), (1
     torch.cuda.synchronize()
     O.conv3x3(x, wt, bi, b, h, w)
     torch.cuda.synchronize()
-    st = ws.view(torch.int64)[-(1 << 17):].cpu().reshape(-1, 8)
+    raw = ws.view(torch.int64)[-(1 << 17):].cpu()
+    st = raw[:65536].reshape(-1, 8)
+    sg = raw[65536:].reshape(-1, 8)
+    sg = sg[sg[:, 7] != 0]
     st = st[st[:, 7] != 0]
     n = st.shape[0]
     t = (st[:, 1:6] - st[:, 0:1]).double()
@@ -35,3 +38,14 @@ for (b, h, w, c) in ((12, 28, 50, 320), (12, 14, 25, 640), (12, 7, 13, 1280), (1
     for i, nm in enumerate(names):
         print("   %-16s median %8.0f cyc = %5.1f us  (p10 %8.0f, p90 %8.0f)" % (nm, t[:, i].median().item(),
               t[:, i].median().item() / clk.median().item() / 1e3, t[:, i].quantile(0.1).item(), t[:, i].quantile(0.9).item()))
+    if sg.shape[0]:
+        for wv, nm in ((0, "early wave 0"), (4, "late  wave 4")):
+            g = sg[sg[:, 6] == wv]
+            if not g.shape[0] or g[0, 5] == 0:
+                continue
+            per = g[:, :5].double() / g[:, 5:6].double()
+            med = per.median(dim=0).values
+            lab = (("(-)", "weight reads + DMA issue", "MFMAs(s) + gathers(s+1)") if wv == 0 else
+                   ("MFMAs(s-1) + gathers(s)", "DMA issue", "weight reads, lgkmcnt(0)"))
+            print("   %s, cycles per steady-state step (median over workgroups): vmcnt wait %4.0f | barrier %4.0f | %s %4.0f | %s %4.0f | %s %4.0f | sum %4.0f" %
+                  (nm, med[0], med[1], lab[0], med[2], lab[1], med[3], lab[2], med[4], med.sum().item()))
