@@ -135,11 +135,11 @@ def dropin_loop(unet, cns, inputs, ts, coefs, steps, g_scale=2.0, start=0, laten
         for j, cn in enumerate(cns):
             down, mid, ctx = cn(lmi, t.expand(2 * b), cam, boxes[j], prompt, conds[j], conditioning_scale=1.0,
                                 guess_mode=False, return_dict=False, use_aug_text=False)
-            if j == 0:
-                down_sum, mid_sum, ctx0 = (list(down), mid, ctx) if len(cns) == 1 else ([d.clone() for d in down], mid.clone(), ctx)
-            else:
+            if j == 0:                                                   # (:421-422: the first branch's tensors, not copies)
+                down_sum, mid_sum, ctx0 = list(down), mid, ctx
+            else:                                                        # (:423-428)
                 down_sum = [a + d for a, d in zip(down_sum, down)]
-                mid_sum = mid_sum + mid
+                mid_sum += mid
         eps = unet(lmi.reshape(2 * b * n, *lmi.shape[2:]), t, encoder_hidden_states=ctx0,
                    down_block_additional_residuals=down_sum, mid_block_additional_residual=mid_sum).sample
         eps = eps.reshape(2, b, n, *eps.shape[1:]).float()

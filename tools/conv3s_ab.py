@@ -8,10 +8,10 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dt, dev = torch.float16, torch.device("cuda")
 O.workspace(512 << 20, dev)
 # (instances, h, w, cin, cout, incumbent, challengers)
-SHAPES = [(12, 28, 50, 320, 320, 39, (45,)), (12, 28, 50, 640, 320, 39, (45,)), (12, 28, 50, 960, 320, 39, (45,)),
-          (12, 14, 25, 640, 640, 31, (32,)), (12, 14, 25, 1280, 640, 31, (32,)), (12, 14, 25, 1920, 640, 31, (32,)),
-          (12, 7, 13, 1280, 1280, 31, (32,)), (12, 7, 13, 2560, 1280, 31, (32,)),
-          (48, 28, 50, 320, 320, 39, (45,)), (48, 14, 25, 640, 640, 31, (32,)), (48, 7, 13, 1280, 1280, 31, (32,))]
+SHAPES = [(12, 28, 50, 320, 320, 39, ()), (12, 28, 50, 640, 320, 39, ()), (12, 28, 50, 960, 320, 39, ()),
+          (12, 14, 25, 640, 640, 31, ()), (12, 14, 25, 1280, 640, 31, ()), (12, 14, 25, 1920, 640, 31, ()),
+          (12, 7, 13, 1280, 1280, 31, ()), (12, 7, 13, 2560, 1280, 31, ()),
+          (48, 28, 50, 320, 320, 39, ()), (48, 14, 25, 640, 640, 31, ()), (48, 7, 13, 1280, 1280, 31, ())]
 for m, h, w, cin, cout, inc, ch in SHAPES:
     rows = m * h * w
     x = torch.randn(rows, cin, device=dev).to(dt)
@@ -38,4 +38,4 @@ for m, h, w, cin, cout, inc, ch in SHAPES:
     for t in res:
         line += (" | t%d cold %6.1f hot %6.1f" % (t, statistics.median(res[t]["cold"]), statistics.median(res[t]["hot"]))
                  if res[t]["cold"] else " | t%d n/a %s" % (t, res[t].get("err", "")))
-    print(line, flush=True)
+    print((os.environ.get("AB_LABEL", "") + " " + line).strip(), flush=True)
