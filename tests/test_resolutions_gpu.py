@@ -3,7 +3,8 @@
 Every other model-level GPU test, the tracked tile table and several kernel preconditions (band conv's LDS budget at
 W = 50, the direct conv's G*H*W <= 384 rows, the 80-row dd_xattn320 tiles) live on the 28x50 pyramid of configs/exp/*.
 The reference also ships 256x704 (32x88 latents: configs/exp-hd/256x704.yaml:11) and 432x768 (54x96:
-configs/exp-hd/432x768.yaml:11, dual_branch_augloss_fusion_8pts_432x768.yaml).  Here: one fp16 multiview-UNet forward
+configs/exp-hd/432x768.yaml:11, dual_branch_augloss_fusion_8pts_432x768.yaml) and 192x384 (24x48:
+configs/exp-drive-wm/192x384.yaml).  Here: one fp16 multiview-UNet forward
 (with ControlNet residuals) and one ControlNet forward per branch kind against the fp32 oracle at those sizes, 6
 view-instances, reduced context; shapes that are not in the tracked table are tuned at run time, dispatchers fall back
 where a fast kernel's precondition fails (tests/test_dispatch_predicates.py checks those predicates without a GPU).
@@ -22,7 +23,7 @@ pytestmark = pytest.mark.gpu
 PAIR = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
 NCAM, NBOX, LTXT = 6, 5, 9
 torch.set_num_threads(min(32, os.cpu_count() or 1))
-RES = [(32, 88), (54, 96)]
+RES = [(32, 88), (54, 96), (24, 48)]
 
 
 def bf16_round(t):
