@@ -28,9 +28,9 @@ class ForwardGraphs:
     """One HIP graph per (input shapes / dtypes / strides, scalar arguments, attribute flags) of a model's public
     forward().  The reference's callers (`pipeline_bev_controlnet.py:405-446,476-484`, `val_set_gen.py`, the runner's
     validation loop) call `controlnet(...)` / `unet(...)` through `forward()`; launched eagerly that is ~270 (ControlNet)
-    / ~290 (UNet) kernel launches from Python per call.  Here the first call with a new key runs once eagerly on the
-    capture stream (tile tuning, weight packing, workspace sizing), records the same code into a graph on STATIC input
-    buffers, and every later call copies its inputs into those buffers (skipped when the caller hands in the static
+    / ~290 (UNet) kernel launches from Python per call.  Here the first call with a new key runs eagerly; the second one
+    runs once more eagerly on the capture stream (tile tuning, weight packing, workspace sizing), records the same code
+    into a graph on STATIC input buffers, and every later call copies its inputs into those buffers (skipped when the caller hands in the static
     output of another forward graph) and replays.  Outputs are views of graph-owned buffers: valid until the next call
     of the same model with the same key — what the sampler loop needs (residuals and tokens are consumed within the
     step); `forward()` clones the 4-channel noise prediction.
@@ -39,12 +39,20 @@ class ForwardGraphs:
     is part of the key, misc/test_utils.py:123-136).  Weights rewritten through `.data` must be followed by
     `model._invalidate()`, as for the packed-weight caches."""
 
+    # A key is recorded the SECOND time it is seen (the first call runs eagerly): a validation loop whose box count —
+    # hence context length — changes with every batch (dataset/utils.py pads to the batch's maximum) would otherwise
+    # pay an eager run AND a capture per call.  At most MAX_ENTRIES graphs per model stay alive (least recently used
+    # goes first): each owns a private memory pool the size of the forward's activations.
+    MAX_ENTRIES = int(os.environ.get("DD_GRAPH_FORWARD_MAX", "6"))
+
     def __init__(self):
-        self.entries = {}
+        self.entries = {}                      # insertion order = recency (re-inserted on every hit)
         self.no_alias = set()
+        self.seen = set()
 
     def clear(self):
         self.entries.clear()
+        self.seen.clear()
 
     @staticmethod
     def flags(module):
@@ -75,8 +83,18 @@ class ForwardGraphs:
             if e is not None and dst:             # one multi-tensor launch per dtype group instead of one copy per input
                 torch._foreach_copy_(dst, src, non_blocking=True)
         if e is None:
+            if key not in self.seen and key not in self.no_alias:
+                if len(self.seen) > 64:
+                    self.seen.clear()
+                self.seen.add(key)
+                return impl(list(tensors))        # first sight: eager, on the caller's tensors
+            self.entries.pop(key, None)
+            while len(self.entries) >= max(1, self.MAX_ENTRIES):
+                self.entries.pop(next(iter(self.entries)))
             e = self._capture(key, tensors, impl)
-            self.entries[key] = e
+        else:
+            self.entries.pop(key)
+        self.entries[key] = e                     # most recently used last
         e["graph"].replay()
         return e["out"]
 

@@ -5,7 +5,9 @@ The reference's callers reach the models only through `controlnet(...)` / `unet(
 models of the bench workload: a replay equals the eager launch of the same call BIT FOR BIT (same kernels, same tile
 table); inputs are refreshed on every call (timestep, latents, residuals); the attribute-poke protocol of
 misc/test_utils.py:123-136 (`use_txt_con_fusion` flipped between calls) selects another graph and flipping back reuses
-the first; `load_state_dict` / `_invalidate` / a processor swap drop the graphs; a foreign processor runs eagerly."""
+the first; `load_state_dict` / `_invalidate` / a processor swap drop the graphs; a foreign processor runs eagerly.  A key
+is recorded the SECOND time it is seen (a loop whose context length changes every batch must not capture per call) and at
+most ForwardGraphs.MAX_ENTRIES graphs stay alive per model."""
 import pytest
 import torch
 
@@ -42,10 +44,12 @@ def test_controlnet_forward_graph_equals_eager_and_follows_attribute_pokes(gpu):
         e_t2 = _cn_call(cn, inputs, 0, t2)
         assert cn.__dict__.get("_fwd_graphs") is None
         cn.graph_forward = True
-        g_first = _cn_call(cn, inputs, 0, t1)                   # records the graph, returns its first replay
+        g_seen = _cn_call(cn, inputs, 0, t1)                    # first sight of the key: eager, nothing recorded
+        graphs = cn.__dict__["_fwd_graphs"]
+        assert len(graphs.entries) == 0 and _same(g_seen, e_t1)
+        g_first = _cn_call(cn, inputs, 0, t1)                   # second sight: records the graph, returns its first replay
         g_again = _cn_call(cn, inputs, 0, t1)                   # pure replay
         g_t2 = _cn_call(cn, inputs, 0, t2)                      # same graph, another timestep
-        graphs = cn.__dict__["_fwd_graphs"]
         assert len(graphs.entries) == 1
         assert _same(g_first, e_t1) and _same(g_again, e_t1) and _same(g_t2, e_t2)
         assert not _same(e_t1[:13], e_t2[:13])                   # the timestep does reach the residuals
@@ -60,6 +64,7 @@ def test_controlnet_forward_graph_equals_eager_and_follows_attribute_pokes(gpu):
         cn.graph_forward = False
         e_nosfa = _cn_call(cn, inputs, 0, t1)
         cn.graph_forward = True
+        _cn_call(cn, inputs, 0, t1)                             # (first sight of the new key)
         g_nosfa = _cn_call(cn, inputs, 0, t1)
         assert _same(g_nosfa, e_nosfa) and not _same(e_nosfa[:13], e_t1[:13]) and len(graphs.entries) == 2
         cn.use_txt_con_fusion = True
@@ -87,14 +92,17 @@ def test_unet_forward_graph_equals_eager_zero_copy_residuals_and_foreign_process
                     mid_block_additional_residual=mid).sample.clone()
 
     with torch.no_grad():
-        down, mid, ctx = cn(lmi, t.expand(2), cam, boxes[0], prompt, conds[0], conditioning_scale=1.0, guess_mode=False,
-                            return_dict=False, use_aug_text=False)          # graph outputs: views of static buffers
+        for _ in range(2):                                      # (the second call records the ControlNet's graph)
+            down, mid, ctx = cn(lmi, t.expand(2), cam, boxes[0], prompt, conds[0], conditioning_scale=1.0, guess_mode=False,
+                                return_dict=False, use_aug_text=False)      # graph outputs: views of static buffers
         unet.graph_forward = False
         e = unet_call(down, mid, ctx)
         e_plain = unet(x, t, encoder_hidden_states=ctx).sample.clone()
         unet.graph_forward = True
+        g0 = unet_call(down, mid, ctx)                          # first sight: eager
         g1 = unet_call(down, mid, ctx)                          # one-branch flow: residuals / tokens read in place
         g2 = unet_call(down, mid, ctx)
+        assert torch.equal(g0, e)
         graphs = unet.__dict__["_fwd_graphs"]
         ent = next(iter(graphs.entries.values()))
         assert any(ent["alias"]) and torch.equal(g1, e) and torch.equal(g2, e)
@@ -108,7 +116,18 @@ def test_unet_forward_graph_equals_eager_zero_copy_residuals_and_foreign_process
         assert torch.equal(g4, unet_call([d * 0.5 for d in down], mid * 0.5, ctx.clone()))
         unet.graph_forward = True
         # no residuals: another key
+        assert torch.equal(unet(x, t, encoder_hidden_states=ctx).sample, e_plain) and len(graphs.entries) == 1
         assert torch.equal(unet(x, t, encoder_hidden_states=ctx).sample, e_plain) and len(graphs.entries) == 2
+        # the cap: the least recently used graph goes when a new key would exceed it
+        cap = type(graphs).MAX_ENTRIES
+        type(graphs).MAX_ENTRIES = 2
+        try:
+            ctx_short = ctx[:, :40].contiguous()                 # another context length: a third key
+            for _ in range(2):
+                y3 = unet(x, t, encoder_hidden_states=ctx_short).sample
+            assert bool(torch.isfinite(y3.float()).all()) and len(graphs.entries) == 2
+        finally:
+            type(graphs).MAX_ENTRIES = cap
         # python-number timestep
         assert torch.equal(unet(x, 981, encoder_hidden_states=ctx).sample, e_plain)
 
