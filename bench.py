@@ -180,6 +180,54 @@ def dropin_leg(args, dtype_name, device, fused_ms_per_step):
     return out
 
 
+def _with_box_count(boxes, n):
+    """The synthetic box dictionaries cut (or repeated) to n boxes per view — what the collate function's padding to the
+    batch maximum (dataset/utils.py:165-244) makes of another sample."""
+    out = []
+    for d in boxes:
+        reps = -(-max(n, 1) // d["bboxes"].shape[2])
+        out.append({k: torch.cat([v] * reps, dim=2)[:, :, :n].contiguous() for k, v in d.items()})
+    return out
+
+
+VARLEN_BOX_COUNTS = (20, 7, 13, 20, 31, 7)
+
+
+def dropin_varlen_leg(args, dtype_name, device, dropin_value):
+    """`dropin_varlen`: the `dropin` loop under the traffic the reference's callers really generate —
+    the box count, hence the context length 78 + N_box, changes from sample to sample (dataset/utils.py:165-244 pads to
+    the batch maximum, pipeline_bev_controlnet.py:349-375 forwards it).  Six 20-step samples with N_box = 20, 7, 13, 20,
+    31, 7 through FRESH models (weights packed by one forward at another bucket, N_box = 40, nothing recorded for the
+    timed shapes): the first-sight eager forwards and every graph capture are INSIDE the timed region.  One graph per
+    model serves the whole 32-box bucket (layers.context_keys), so the run records 3 graphs in all."""
+    from dualdiff_amd.pipeline.pipeline_bev_controlnet import ddim_schedule
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    unet, cns = build_models(dtype, device)
+    lat, prompt, cam, boxes, conds = synthetic_inputs(1, dtype, device, seed=1234)
+    ts, coefs = ddim_schedule(20)
+    ts = ts.to(device)
+    coefs = coefs.tolist()
+    with torch.no_grad():
+        dropin_loop(unet, cns, (lat, prompt, cam, _with_box_count(boxes, 40), conds), ts, coefs, 1)   # packs the weights
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for n in VARLEN_BOX_COUNTS:
+            out = dropin_loop(unet, cns, (lat, prompt, cam, _with_box_count(boxes, n), conds), ts, coefs, 20)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    steps = 20 * len(VARLEN_BOX_COUNTS)
+    fg = [m.__dict__.get("_fwd_graphs") for m in cns + [unet]]
+    res = {"value": steps / el, "unit": "steps/s", "ms_per_step": el / steps * 1e3, "box_counts": list(VARLEN_BOX_COUNTS),
+           "steps_per_sample": 20, "captures": [0 if g is None else g.captures for g in fg],
+           "vs_dropin": (round(steps / el / dropin_value, 3) if dropin_value else None),
+           "outputs_finite": bool(torch.isfinite(out.float()).all().item()),
+           "loop": "six 20-step samples through the public forward() surfaces, another box count per sample; first-sight "
+                   "eager forwards and graph captures inside the timed region"}
+    del unet, cns
+    torch.cuda.empty_cache()
+    return res
+
+
 def _cpu_models():
     """fp32 CPU oracle models (kind 'port': restated diffusers blocks + reference-owned blocks, oracle/) with cheap
     seeded weights: matrices / conv kernels ~ N(0, 0.02^2) (SURVEY §8d's synthetic-weight rule; drawn once into a
@@ -305,6 +353,12 @@ def cpu_baseline(full_steps=2, budget_s=150.0):
             "config2_step_seconds_all": t2, "bf16": bf16, "seconds_spent": time.perf_counter() - t_begin}
 
 
+def dd_env():
+    """Every DD_* variable set in this process, as "NAME=value" (VERDICT r5 item 6): switches such as DD_PERSIST /
+    DD_FUSED_TOKENS / DD_GRAPH_FORWARD change what a run measures, so the line says which were set (the driver's run: [])."""
+    return sorted("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith("DD_"))
+
+
 def _metric_name():
     try:
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
@@ -344,7 +398,7 @@ def _pmc_table():
     """Committed rocprofv3 --pmc summary (FETCH_SIZE x2 + WRITE_SIZE, separate passes, tools/pmc_summary.py +
     tools/refresh_profiles.sh): this round's if present, else the previous round's."""
     base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(base, name)) as f:
                 return json.load(f)["kernels"], name
@@ -621,20 +675,21 @@ def compact_line(full, full_path=None, limit=LINE_LIMIT):
     c = full.get("cpu_baseline")
     if c:
         out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
-                               "sample": c["sample"][:400]}
+                               "sample": c["sample"][:300]}
         b = (c.get("bf16") or {}).get("value")
         if b:
             out["cpu_baseline"]["bf16_value"] = b
     else:
         out["cpu_baseline"] = None
-    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling", "batched", "unipc20", "dropin"):
+    out["env"] = full.get("env", [])
+    for k in ("other_dtype", "speedup_vs_cpu", "strong_scaling", "batched", "unipc20", "dropin", "dropin_varlen", "collective"):
         if full.get(k) is not None:
             out[k] = dict(full[k]) if isinstance(full[k], dict) else full[k]
     if isinstance(out.get("batched"), dict):
         out["batched"].pop("roofline_classes", None)              # the full class table stays in the report file
-    for k in ("unipc20", "dropin"):
+    for k in ("unipc20", "dropin", "dropin_varlen"):
         if isinstance(out.get(k), dict):
-            for kk in ("sampler", "loop"):
+            for kk in ("sampler", "loop", "steps_per_sample"):
                 out[k].pop(kk, None)
     for k in ("view_split", "frame_split"):
         if k in cfg:
@@ -648,6 +703,7 @@ def compact_line(full, full_path=None, limit=LINE_LIMIT):
                  lambda o: isinstance(o.get("batched"), dict) and o["batched"].get("roofline") and o["batched"]["roofline"].pop("next", None),
                  lambda o: o.pop("unipc20", None),
                  lambda o: o.pop("batched", None),
+                 lambda o: o.pop("dropin_varlen", None),
                  lambda o: o.pop("dropin", None),
                  lambda o: o.pop("strong_scaling", None),
                  lambda o: o["config"].pop("view_split", None) or o["config"].pop("frame_split", None),
@@ -799,6 +855,20 @@ def _self_launch(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def rank_sum_check(dist, device=None):
+    """{backend, world_size, rank_sum, rank_sum_check}: all ranks all-reduce their rank id (on `device` for RCCL, on the
+    host for gloo); the sum must be world * (world - 1) / 2 — a job whose ranks silently formed separate groups, or a
+    backend that fell back, shows here."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.tensor([rank], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t)
+    if device is not None:
+        torch.cuda.synchronize()
+    total = int(t.item())
+    return {"backend": dist.get_backend(), "world_size": world, "rank_sum": total,
+            "rank_sum_check": total == world * (world - 1) // 2}
+
+
 def _plumbing_check(args, world, rank):
     """Launcher / rendezvous check WITHOUT the measured path (runs on a CPU-only host: tests/test_distributed_cpu.py):
     every rank joins a gloo group, passes the barrier the timed region uses and takes the max-over-ranks of a fake
@@ -806,9 +876,11 @@ def _plumbing_check(args, world, rank):
     the default mode the strong-scaling leg is orchestrated exactly as in a real run (child job, timeout, one line)."""
     import torch.distributed as dist
     from dualdiff_amd.parallel import max_over_ranks
+    collective = None
     if world > 1:
         dist.init_process_group("gloo")
         dist.barrier()
+        collective = rank_sum_check(dist)
     slowest = max_over_ranks(1.0 + rank)
     time.sleep(float(os.environ.get("DD_PLUMBING_SLEEP", "0")))          # tests: a child job that overruns its timeout
     if world > 1:
@@ -818,7 +890,9 @@ def _plumbing_check(args, world, rank):
         return
     out = {"metric": _metric_name(), "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "plumbing_check": True, "slowest_rank_seconds": slowest, "requested_gpus": args.gpus,
-           "parallelism": args.parallelism}
+           "parallelism": args.parallelism, "env": dd_env()}
+    if collective is not None:
+        out["collective"] = collective
     if world > 1 and args.parallelism == "scenes" and args.strong_leg == "auto":
         out["strong_scaling"] = strong_scaling_leg(world, args, 1.0)
     print(json.dumps(out), flush=True)
@@ -887,7 +961,13 @@ def main():
                     help="seconds the strong-scaling child job may take before its process group is killed")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="launcher / rendezvous check only (gloo, no GPU call, no measurement): prints n_gpus")
+    ap.add_argument("--allow-alt-lib", action="store_true",
+                    help="accept DD_HIP_LIB (an alternative build of the C-ABI library, A/B experiments); without this flag a "
+                         "set DD_HIP_LIB is refused: a bench line must not silently come from another binary")
     args = ap.parse_args()
+    if os.environ.get("DD_HIP_LIB") and not args.allow_alt_lib:
+        raise SystemExit("bench.py: DD_HIP_LIB=%s is set; pass --allow-alt-lib to measure an alternative library build "
+                         "(the line then lists it under `env`)" % os.environ["DD_HIP_LIB"])
 
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -918,6 +998,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+
+    # N > 1: evidence that the collective backend saw every rank — one all-reduce of the rank ids on
+    # the device path, OUTSIDE the timed region
+    collective = rank_sum_check(dist, device if backend == "nccl" else None) if dist is not None else None
 
     from dualdiff_amd import ops as O
     if args.retune:
@@ -961,7 +1045,7 @@ def main():
         if kt:
             os.environ["DD_BENCH_KERNEL_TABLE"] = kt
     # the sampler the reference's test pipeline really runs (misc/test_utils.py:161-162: UniPC, 20 steps), fused form
-    unipc = dropin = None
+    unipc = dropin = dropin_varlen = None
     if (world == 1 and args.parallelism == "scenes" and args.scenes == 1 and args.frames == 1 and not args.fp8_weights
             and not args.lora_rank and not args.no_graph and not args.no_extra_legs):
         uargs = argparse.Namespace(**vars(args))
@@ -977,6 +1061,10 @@ def main():
             dropin = dropin_leg(args, args.dtype, device, res["elapsed"] / args.steps * 1e3)
         except Exception as e:
             dropin = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        try:
+            dropin_varlen = dropin_varlen_leg(args, args.dtype, device, (dropin or {}).get("value"))
+        except Exception as e:
+            dropin_varlen = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     want_strong = world > 1 and args.parallelism == "scenes" and args.strong_leg == "auto"
     if dist is not None:                       # the weak-scaling job is over: every rank leaves the group and frees its GPU memory
         torch.cuda.empty_cache()
@@ -1058,6 +1146,11 @@ def main():
         out["unipc20"] = unipc
     if dropin is not None:
         out["dropin"] = dropin
+    if dropin_varlen is not None:
+        out["dropin_varlen"] = dropin_varlen
+    out["env"] = dd_env()
+    if collective is not None:
+        out["collective"] = collective
     path = _write_full_report(out, "%s_n%d_%s" % (args.dtype, world, args.parallelism))
     line = json.dumps(compact_line(out, path))
     assert len(line) < LINE_LIMIT, len(line)

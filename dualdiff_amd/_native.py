@@ -51,6 +51,7 @@ class AttnDesc(Structure):
         ("q_head_stride", c_int64), ("k_head_stride", c_int64), ("v_head_stride", c_int64),
         ("q_prescaled", c_int32),
         ("kv_batch_map2", c_void_p),
+        ("lk_dev", c_void_p),
     ]
 
 
@@ -77,6 +78,7 @@ class XAttnDesc(Structure):
         ("instances", c_int32), ("rows_per_inst", c_int32), ("lk", c_int32),
         ("channels", c_int32), ("heads", c_int32), ("scale", c_float), ("dtype", c_int32),
         ("ln_out", c_void_p), ("ld_ln_out", c_int64), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("lk_dev", c_void_p),
     ]
 
 
@@ -149,7 +151,7 @@ SIGNATURES = {
                                    c_int64, c_int32, c_void_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIB = None
 
 

@@ -46,6 +46,7 @@ struct AttnParams {
   int64_t qhs, khs, vhs;   // head strides (elements)
   int prescaled;           // q carries scale * log2(e)
   const int32_t* kv_map2;  // second K/V batch map: O = Attn(q, kv[map]) + Attn(q, kv[map2]) in ONE launch (v5 family)
+  const int32_t* lk_dev;   // key count read from DEVICE memory at kernel start (dd_attn_desc.lk_dev); p.lk is then the capacity
 };
 
 
@@ -92,6 +93,9 @@ void dd_attn5_kernel(const AttnParams p) {
   const int wave = tid >> 6;
   const int g = lane >> 4;
   const int c = lane & 15;
+  // keys per batch entry: a kernel argument, or (lk_dev) one word of device memory read here — a HIP graph recorded
+  // at a context CAPACITY then serves every length up to it (model_base.ForwardGraphs).  Uniform: a scalar load.
+  const int lk = p.lk_dev ? min(max(__builtin_amdgcn_readfirstlane(*p.lk_dev), 1), p.lk) : p.lk;   // clamped to the capacity
 
   const int nqb = p.nqb;
   const int nwg = nqb * p.batch * p.heads;
@@ -160,16 +164,16 @@ void dd_attn5_kernel(const AttnParams p) {
   f32x4 oacc[DVT][QT];
   float m_run[QT], l_run[QT];
   f32x4 cinit[QT];                       // PRE: -m_run broadcast, the C operand of the first QK^T MFMA
-  const int ntiles = (p.lk + KV_TILE - 1) / KV_TILE;
+  const int ntiles = (lk + KV_TILE - 1) / KV_TILE;
 
   for (int pass = 0; pass < npass; ++pass) {
   const int kb = pass ? p.kv_map2[b] : (p.kv_map ? p.kv_map[b] : b);
   const T* kbase = reinterpret_cast<const T*>(p.k) + (int64_t)kb * p.kbs + h * p.khs;
   const T* vbase = reinterpret_cast<const T*>(p.v) + (int64_t)kb * p.vbs + h * p.vhs;
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(kbase), 0, (uint32_t)(p.lk - 1) * k_row_bytes + D * sizeof(T), 0x00020000);
+      const_cast<T*>(kbase), 0, (uint32_t)(lk - 1) * k_row_bytes + D * sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(vbase), 0, (uint32_t)(p.lk - 1) * v_row_bytes + D * sizeof(T), 0x00020000);
+      const_cast<T*>(vbase), 0, (uint32_t)(lk - 1) * v_row_bytes + D * sizeof(T), 0x00020000);
 #pragma unroll
   for (int i = 0; i < DVT; ++i)
 #pragma unroll
@@ -180,7 +184,7 @@ void dd_attn5_kernel(const AttnParams p) {
   for (int j = 0; j < QT; ++j) cinit[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (pass) {
     __syncthreads();                     // every wave is done with the first pass's last tile
-    if (ONES && (p.lk % KV_TILE) != 0) { // ... whose ragged rows lost their ones entry: restore the column
+    if (ONES && (lk % KV_TILE) != 0) { // ... whose ragged rows lost their ones entry: restore the column
       const T one_t = (T)1.0f;
       unsigned short one_u16;
       __builtin_memcpy(&one_u16, &one_t, 2);
@@ -224,9 +228,9 @@ void dd_attn5_kernel(const AttnParams p) {
     const T* Vs = tile + KV_TILE * KSTR;
     if (NBUF == 1) __syncthreads();       // previous tile fully consumed by every wave
     store_kv(tile);
-    if (ONES && tile0 + KV_TILE > p.lk) { // last, ragged tile: rows past lk lose their ones entry
+    if (ONES && tile0 + KV_TILE > lk) { // last, ragged tile: rows past lk lose their ones entry
       const u32x4 zero = {0u, 0u, 0u, 0u};
-      if (tid < KV_TILE && tile0 + tid >= p.lk) dd_st16(tile + KV_TILE * KSTR + tid * VSTR + DCH * 8, zero);
+      if (tid < KV_TILE && tile0 + tid >= lk) dd_st16(tile + KV_TILE * KSTR + tid * VSTR + DCH * 8, zero);
     }
     __syncthreads();                      // tile visible (NBUF == 2: and the other buffer is free)
     if (it + 1 < ntiles) load_kv(tile0 + KV_TILE);
@@ -234,7 +238,7 @@ void dd_attn5_kernel(const AttnParams p) {
 #pragma unroll
     for (int cc = 0; cc < KV_TILE / 32; ++cc) {
       const int key0 = tile0 + cc * 32;
-      if (key0 >= p.lk) break;
+      if (key0 >= lk) break;
       f32x4 sacc[2][QT];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -249,7 +253,7 @@ void dd_attn5_kernel(const AttnParams p) {
             sacc[t][j] = dd_mfma16(kf[t], qf[j][ks],
                                    ks == 0 ? (PRE ? cinit[j] : f32x4{0.f, 0.f, 0.f, 0.f}) : sacc[t][j]);
       }
-      const bool tail = key0 + 32 > p.lk;             // uniform
+      const bool tail = key0 + 32 > lk;             // uniform
       V8 pf[QT];
 #pragma unroll
       for (int j = 0; j < QT; ++j) {
@@ -259,7 +263,7 @@ void dd_attn5_kernel(const AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[t * 4 + r] = sacc[t][j][r];
         auto mask_tail = [&]() {
-          int rem = p.lk - key0 - g * 4;       // pinned here: the compiler otherwise hoists the eight
+          int rem = lk - key0 - g * 4;       // pinned here: the compiler otherwise hoists the eight
           asm volatile("" : "+v"(rem));        // compares of this rare path into the common block
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -534,6 +538,8 @@ int attn_prepare(const dd_attn_desc* d, AttnParams& p) {
   if ((p.qhs & 7) || (p.khs & 7) || (p.vhs & 7)) return DD_ERR_BAD_ARG;
   p.prescaled = d->q_prescaled ? 1 : 0;
   if (d->q_prescaled) p.scale_log2 = 1.0f;
+  p.lk_dev = d->lk_dev;
+  if (d->lk_dev && (reinterpret_cast<uintptr_t>(d->lk_dev) & 3u)) return DD_ERR_BAD_ARG;
   return DD_OK;
 }
 

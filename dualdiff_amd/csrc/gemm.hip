@@ -1990,9 +1990,13 @@ Plan make_plan(const dd_gemm_desc* d) {
     if (geglu && kTiles[ti].tn % 4 != 0) ti = 2;
   }
   if (d->ln_colsum) {                                // LayerNorm fold lives in the LDS-DMA family only
-    if (d->tile <= 0) {                              // heuristic picked a register-staged tile: take its twin
-      const int twin[4] = {11, 17, 14, 18};
-      for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == twin[ti < 4 ? ti : 3]) { ti = i; break; }
+    if (d->tile <= 0) {                              // heuristic picked a register-staged tile: take its LDS-DMA twin
+      // (the same wave / block shape on a dd_gemm2 ring, 0 < stages < 100; round 5 removed the 2-slot 128x64 / 64x64
+      //  tiles the old table {11, 17, 14, 18} pointed at, so the twin is looked up by shape)
+      const TileCfg& h = kTiles[ti < 4 ? ti : 3];
+      for (int i = 0; i < kNumTiles; ++i)
+        if (kTiles[i].stages > 0 && kTiles[i].stages < 100 && kTiles[i].wm == h.wm && kTiles[i].wn == h.wn &&
+            kTiles[i].tm == h.tm && kTiles[i].tn == h.tn) { ti = i; break; }
     }
     if (kTiles[ti].stages <= 0 || kTiles[ti].stages >= 100 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }

@@ -50,6 +50,7 @@ struct XAttnParams {
   void* out; int64_t ldo;
   void* ln_out; int64_t ld_ln; const void* ln_g; const void* ln_b; float ln_eps;   // optional second output
   int inst, n, lk;                       // view-instances, query rows per instance, keys per instance
+  const int32_t* lk_dev;                 // keys per instance from device memory (lk = the capacity), or NULL
   int tiles;                             // ceil(n / 80)
   float qscale;                          // softmax scale * log2(e)
   int dbg;                               // DD_XATTN_DBG (diagnostics): 1 skip phase 2, 2 skip the MFMAs of the products, 4 skip softmax
@@ -92,6 +93,9 @@ void dd_xattn320_kernel(const XAttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15;
   const int g = lane >> 4;
+  // keys per instance: a kernel argument, or (lk_dev) a word of device memory read here (dd_xattn_desc.lk_dev): p.lk is
+  // then the CAPACITY the instance strides were built for — one captured launch serves every context length up to it
+  const int lk = p.lk_dev ? min(max(__builtin_amdgcn_readfirstlane(*p.lk_dev), 1), p.lk) : p.lk;
 
   const int inst = blockIdx.x / p.tiles;
   const int t = blockIdx.x - inst * p.tiles;
@@ -106,10 +110,10 @@ void dd_xattn320_kernel(const XAttnParams p) {
   const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wo), 0, XC * XC * sizeof(T), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(reinterpret_cast<const T*>(p.k) + (int64_t)inst * p.k_is), 0,
-      (uint32_t)(((int64_t)(p.lk - 1) * p.ldk + (XH - 1) * p.k_hs + XD) * sizeof(T)), 0x00020000);
+      (uint32_t)(((int64_t)(lk - 1) * p.ldk + (XH - 1) * p.k_hs + XD) * sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(reinterpret_cast<const T*>(p.v) + (int64_t)inst * p.v_is), 0,
-      (uint32_t)(((int64_t)(p.lk - 1) * p.ldv + (XH - 1) * p.v_hs + XD) * sizeof(T)), 0x00020000);
+      (uint32_t)(((int64_t)(lk - 1) * p.ldv + (XH - 1) * p.v_hs + XD) * sizeof(T)), 0x00020000);
 
   // ---- DMA issue helpers (every wave issues the same NUMBER of instructions per call: the counted waits rely on it) ----
   // x tile: 80 rows x 41 chunk slots = 3280 slots -> 52 wave instructions (6 per wave for waves 0-1, 5 for the rest:
@@ -148,7 +152,7 @@ void dd_xattn320_kernel(const XAttnParams p) {
       const int key = rem / 5, ch = rem - key * 5;
       const int head = round * 2 + hh;
       unsigned char* kdst = reinterpret_cast<unsigned char*>(ring + buf * KVBUF) + wi * 1024;
-      const bool in = key < p.lk;                              // keys past lk: zeros (another instance's rows follow)
+      const bool in = key < lk;                              // keys past lk: zeros (another instance's rows follow)
       xdma16(rs_k, in ? (uint32_t)((key * (int)p.ldk + head * (int)p.k_hs + ch * 8) * 2) : X_OOB, 0, kdst);
       xdma16(rs_v, in ? (uint32_t)((key * (int)p.ldv + head * (int)p.v_hs + ch * 8) * 2) : X_OOB, 0, kdst + XLK * XD * 2 * 2);
     }
@@ -218,7 +222,7 @@ void dd_xattn320_kernel(const XAttnParams p) {
 
   // ---- phase 2: attention, two heads per round (round r in buffer (r + 1) & 1) ------------------------------------
   const int rb = wave % 5, hp = wave / 5;
-  const int nkb = (p.lk + 15) >> 4;                            // 16-key blocks (<= 8)
+  const int nkb = (lk + 15) >> 4;                            // 16-key blocks (<= 8)
   const T* resb = p.res ? reinterpret_cast<const T*>(p.res) + grow0 * p.ldres : nullptr;
   V4 rv[2][5], bv[2];                                          // residual and bias: loaded under the last round
 #pragma unroll 1
@@ -275,7 +279,7 @@ void dd_xattn320_kernel(const XAttnParams p) {
       if (b < nkb) {                                           // (uniform) blocks past the last key cost nothing
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (b * 16 + g * 4 + r >= p.lk) s[b][r] = -INFINITY;
+          if (b * 16 + g * 4 + r >= lk) s[b][r] = -INFINITY;
           mx = fmaxf(mx, s[b][r]);
         }
       }
@@ -510,6 +514,8 @@ extern "C" int dd_xattn320(const dd_xattn_desc* d, dd_stream_t stream) {
   p.out = d->out; p.ldo = d->ldo;
   p.ln_out = d->ln_out; p.ld_ln = d->ld_ln_out; p.ln_g = d->ln_gamma; p.ln_b = d->ln_beta; p.ln_eps = d->ln_eps;
   p.inst = d->instances; p.n = d->rows_per_inst; p.lk = d->lk;
+  p.lk_dev = d->lk_dev;
+  if (d->lk_dev && (reinterpret_cast<uintptr_t>(d->lk_dev) & 3u)) return DD_ERR_BAD_ARG;
   p.tiles = (d->rows_per_inst + XR - 1) / XR;
   p.qscale = d->scale * 1.44269504088896340736f;
   { static const int dbg = getenv("DD_XATTN_DBG") ? atoi(getenv("DD_XATTN_DBG")) : 0; p.dbg = dbg; }

@@ -46,15 +46,21 @@ def fold_lora_(model, lora_state_dict, scale=1.0, network_alphas=None):
     # `network_alphas` as diffusers' loaders hand it over: keys '<prefix>.<attention path>.processor.<proj>_lora.down.weight
     # .alpha', '<...>.<proj>_lora.alpha' or the bare stem, with an optional 'unet.' prefix — normalised to the stem;
     # entries that match no folded pair are an error (a silently ignored alpha is a silently wrong LoRA scale)
+    # The loader hands over the WHOLE mapping, other networks included: entries under a foreign prefix ('text_encoder.',
+    # 'text_encoder_2.', ...) are not this model's and are skipped; the strictness applies to 'unet.' / bare keys.
     alphas = {}
     for k, v in (network_alphas or {}).items():
+        if k.startswith(("text_encoder", "te.", "lora_te", "vae.", "controlnet.")):
+            continue
         kk = k[len("unet."):] if k.startswith("unet.") else k
         for suf in (".alpha", ".network_alpha"):
             if kk.endswith(suf):
                 kk = kk[: -len(suf)]
-        for suf in ("_lora.down.weight", "_lora.up.weight", "_lora"):
+        for suf in (".lora.down.weight", ".lora.up.weight", "_lora.down.weight", "_lora.up.weight", "_lora", ".lora"):
             if kk.endswith(suf):
                 kk = kk[: -len(suf)]
+        if kk.endswith(".to_out.0"):                  # 'attn1.to_out.0[.lora ...]': the Linear inside the ModuleList
+            kk = kk[: -len(".0")]
         if ".processor." not in kk and kk.rsplit(".", 1)[-1] in ("to_q", "to_k", "to_v", "to_out"):
             path, proj = kk.rsplit(".", 1)
             kk = path + ".processor." + proj

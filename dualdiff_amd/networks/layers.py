@@ -41,6 +41,74 @@ class _Cached(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
 
+# ---- context length in device memory (round 6) ----------------------------------------------------------------
+# The context a cross-attention reads is [camera token | 77 text tokens | N_box box tokens] per view-instance
+# (unet_addon_rawbox.py:337-361,1065-1068), and N_box changes from sample to sample: the reference's collate function pads
+# the boxes of a batch to that batch's maximum (dataset/utils.py:165-244) and the pipeline forwards that length
+# (pipeline_bev_controlnet.py:349-375).  The public forward()s therefore lay the context out at a CAPACITY — the box
+# count rounded up to CTX_BUCKET — and hand the real length to the attention kernels through one int32 in device memory
+# (dd_attn_desc.lk_dev), so that ONE recorded HIP graph per capacity serves every length (model_base.ForwardGraphs).
+# Keys past the real length are never read: they are not "masked null boxes" (null box tokens DO attend in the
+# reference, unet_addon_rawbox.py:852-896), they do not exist.
+CTX_BASE = 78          # camera token + the 77 CLIP text tokens: the box-free context of every DualDiff config
+CTX_BUCKET = 32        # box-token capacities are multiples of this
+
+
+def box_capacity(n_box):
+    """Capacity (in box tokens) of the bucket that holds `n_box` boxes: 0 -> 32, 1..32 -> 32, 33..64 -> 64, ..."""
+    return max(CTX_BUCKET, -(-int(n_box) // CTX_BUCKET) * CTX_BUCKET)
+
+
+def ctx_capacity(lc):
+    """Context capacity for a context of `lc` tokens handed to the UNet: contexts shorter than CTX_BASE (plain SD use:
+    text only) keep their exact length, longer ones are [CTX_BASE | boxes] and get the box bucket's capacity."""
+    return int(lc) if lc < CTX_BASE else CTX_BASE + box_capacity(lc - CTX_BASE)
+
+
+_CTX_KEYS = __import__("threading").local()
+
+
+class context_keys:
+    """`with context_keys(ctx, capacity, lk_dev):` — inside, every cross-attention whose context lies in `ctx`'s memory
+    and is `capacity` tokens long reads only the first lk_dev[0] of them (Attention.run_cross).  Matched by address
+    range, not identity: the processor protocol reshapes and SPLIT_SIZE chunks the context on its way down."""
+
+    def __init__(self, ctx, capacity, lk_dev):
+        self.new = None if lk_dev is None else (ctx.data_ptr(), ctx.data_ptr() + ctx.numel() * ctx.element_size(),
+                                                int(capacity), lk_dev)
+
+    def __enter__(self):
+        self.old = getattr(_CTX_KEYS, "cur", None)
+        _CTX_KEYS.cur = self.new
+        return self
+
+    def __exit__(self, *exc):
+        _CTX_KEYS.cur = self.old
+        return False
+
+
+def lk_dev_for(ctx2d, lk):
+    cur = getattr(_CTX_KEYS, "cur", None)
+    if cur is None or lk != cur[2] or not (cur[0] <= ctx2d.data_ptr() < cur[1]):
+        return None
+    return cur[3]
+
+
+_LK_CONST = {}
+
+
+def lk_const(value, device):
+    """int32 device tensor [1] holding `value` — one per (device, value), created outside any capture and kept for the
+    life of the process (a forward graph copies it into its own static word, an eager call reads it in place)."""
+    key = (str(device), int(value))
+    t = _LK_CONST.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("lk_const(%d) first requested inside a stream capture" % value)
+        t = _LK_CONST[key] = torch.tensor([int(value)], dtype=torch.int32, device=device)
+    return t
+
+
 def _pad_cols(w, mult=8):
     k = w.shape[1]
     kp = (k + mult - 1) // mult * mult
@@ -535,6 +603,7 @@ class Attention(_Cached):
                     kv.record_stream(torch.cuda.current_stream())
         if kv is None:
             kv = self.project_kv(ctx2d)
+        lk_dev = lk_dev_for(ctx2d, lk)               # the context is laid out at a capacity: its real length (round 6)
         if XATTN_FUSED and O.xattn320_ok(c, self.heads, lk, x2d.shape[0]) and self.to_q.in_features == c and self.to_q.bias is None \
                 and not ln_stats and LN_FOLD == "0":
             # 28x50 level: q-projection, attention over the <= 128 context keys and out-projection + residual in ONE
@@ -542,7 +611,7 @@ class Attention(_Cached):
             xn = x2d if norm is None else norm.run(x2d)
             lno = (ln_next.weight, ln_next.bias, ln_next.eps) if LN_PRODUCER and isinstance(ln_next, LayerNorm) else None
             out = O.xattn320(xn, self.to_q.wx, self.to_out[0].wx, self.to_out[0].bias, kv[:, :c], kv[:, c:], batch, lq,
-                             lk, self.scale, res=res, ln_out=lno)
+                             lk, self.scale, res=res, ln_out=lno, lk_dev=lk_dev)
             if lno is not None:
                 out._ln_cache = (ln_next, out._ln_out)
             return out
@@ -550,7 +619,7 @@ class Attention(_Cached):
         kw = {"head_major": self._hm(self.heads)} if q_hm else {}
         q = self.to_q.run(x2d, **kw) if norm is None else self.to_q.run_ln(x2d, norm, **kw)
         o = O.attention(q, kv[:, :c], kv[:, c:], batch, lq, lk, self.heads, self.dim_head, self.scale,
-                        q_prescaled=q_hm)
+                        q_prescaled=q_hm, lk_dev=lk_dev)
         return self.to_out[0].run(o, res=res, ln_stats=ln_stats, ln_next=ln_next)
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):

@@ -18,6 +18,9 @@ from .layers import HIPAttnProcessor, TimeEmbProjBank
 # HIP graphs behind the public forward() surfaces (round 5).  DD_GRAPH_FORWARD=0 switches them off process-wide,
 # `model.graph_forward = False` per model.
 GRAPH_FORWARD = os.environ.get("DD_GRAPH_FORWARD", "1") != "0"
+# Context laid out at a bucket capacity, real length in device memory (layers.context_keys); DD_VARLEN_CONTEXT=0: every
+# context length is its own shape (and its own forward graph), as in round 5.
+VARLEN_CONTEXT = os.environ.get("DD_VARLEN_CONTEXT", "1") != "0"
 # data_ptr -> static output tensor of a live forward graph: a caller that hands such a tensor straight to the next
 # model (ControlNet residuals / tokens -> UNet, as pipeline_bev_controlnet.py:476-484 does with one branch) is read in
 # place instead of through a copy.  Weak: the entries die with the graph that owns the buffers.
@@ -31,41 +34,67 @@ class ForwardGraphs:
     / ~290 (UNet) kernel launches from Python per call.  Here the first call with a new key runs eagerly; the second one
     runs once more eagerly on the capture stream (tile tuning, weight packing, workspace sizing), records the same code
     into a graph on STATIC input buffers, and every later call copies its inputs into those buffers (skipped when the caller hands in the static
-    output of another forward graph) and replays.  Outputs are views of graph-owned buffers: valid until the next call
-    of the same model with the same key — what the sampler loop needs (residuals and tokens are consumed within the
-    step); `forward()` clones the 4-channel noise prediction.
-    Invalidation: `load_state_dict` / `.to()` / `set_attn_processor` on the model (`_invalidate`), any packed-weight
-    drop anywhere below it (layers.CACHE_EPOCH), and attribute pokes such as `use_txt_con_fusion` (the flag snapshot
-    is part of the key, misc/test_utils.py:123-136).  Weights rewritten through `.data` must be followed by
-    `model._invalidate()`, as for the packed-weight caches."""
+    output of another forward graph) and replays.
 
-    # A key is recorded the SECOND time it is seen (the first call runs eagerly): a validation loop whose box count —
-    # hence context length — changes with every batch (dataset/utils.py pads to the batch's maximum) would otherwise
-    # pay an eager run AND a capture per call.  At most MAX_ENTRIES graphs per model stay alive (least recently used
-    # goes first): each owns a private memory pool the size of the forward's activations.
+    OUTPUTS (round 6): by default the caller gets its OWN copies (one multi-tensor copy per call), like the
+    fresh tensors the reference returns — a caller that keeps the results of two same-shaped calls (separate uncond /
+    cond passes, two conditions through one net, a step-to-step comparison) must not find call 1's tensors holding call
+    2's values.  `model.graph_forward = "alias"` hands out views of the graph-owned buffers instead (valid until the
+    next call of that model with the same key): what a sampler loop that consumes the residuals within the step can opt
+    into — the next model then reads them in place.
+
+    CONTEXT LENGTH (round 6): the shapes in the key are those of the CAPACITY layout (layers.box_capacity: box counts in
+    buckets of 32), and the real length travels as one int32 input tensor — one graph per bucket serves every box count
+    in it (dataset/utils.py:165-244 pads the boxes to each batch's maximum, so the count changes from sample to sample).
+
+    Invalidation: `load_state_dict` / `.to()` / `set_attn_processor` on the model (`_invalidate`), any packed-weight
+    drop anywhere below it (layers.CACHE_EPOCH), attribute pokes such as `use_txt_con_fusion` and nulled sub-modules such as
+    `controlnet_cond_embedding = None` (the flag snapshot is part of the key, misc/test_utils.py:123-136).  Weights
+    rewritten through `.data` must be followed by `model._invalidate()`, as for the packed-weight caches.
+    A capture that fails (a non-capturable op in a user-modified block, no memory for the private pool) marks its key
+    eager-only: the call and every later one with that key run eagerly, with one warning.
+    Replays of graphs captured on recycled side streams share ops.workspace buffers: they are safe because all replays of
+    one process are launched from the caller's CURRENT stream, one after the other — do not replay forward graphs of one
+    model concurrently from several streams."""
+
+    # A key is recorded the SECOND time it is seen (the first call runs eagerly): a caller that uses a shape once
+    # should not pay an eager run AND a capture for it.  At most MAX_ENTRIES graphs per model stay alive (least
+    # recently used goes first): each owns a private memory pool the size of the forward's activations.
     MAX_ENTRIES = int(os.environ.get("DD_GRAPH_FORWARD_MAX", "6"))
 
     def __init__(self):
         self.entries = {}                      # insertion order = recency (re-inserted on every hit)
         self.no_alias = set()
         self.seen = set()
+        self.eager_only = set()                # keys whose capture failed
+        self.captures = 0                      # graphs recorded over the life of this cache (bench: dropin_varlen)
 
     def clear(self):
         self.entries.clear()
         self.seen.clear()
+        self.eager_only.clear()
 
     @staticmethod
     def flags(module):
-        """The scalar attributes of the model (the poke protocol) plus the one module-level knob of the reference that
-        changes what a forward launches: box_adapter.SPLIT_SIZE (box_adapter.py:11, chunked attention calls)."""
-        from . import box_adapter
+        """Everything outside the tensors that changes what a forward launches: the scalar attributes of the model (the
+        poke protocol), WHICH registered sub-modules are None (`controlnet_cond_embedding`, `txt_con_fusionp`, `adm_proj`
+        are nulled by the reference's loader, misc/test_utils.py:123-136 — they live in `_modules`, not in vars()),
+        box_adapter.SPLIT_SIZE (box_adapter.py:11, chunked attention calls) and this package's own module-level
+        switches.  `use_aug_text` is an argument of every call (and written back by prepare_tokens): not a flag."""
+        from . import box_adapter, unet_addon_rawbox
         return tuple(sorted((k, v) for k, v in vars(module).items()
-                            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str, type(None))))) \
-            + (("SPLIT_SIZE", box_adapter.SPLIT_SIZE),)
+                            if not k.startswith("_") and k not in ("training", "use_aug_text")
+                            and isinstance(v, (bool, int, float, str, type(None))))) \
+            + tuple(sorted((k, v is None) for k, v in module._modules.items())) \
+            + (("SPLIT_SIZE", box_adapter.SPLIT_SIZE), ("XATTN_FUSED", _layers.XATTN_FUSED),
+               ("LN_PRODUCER", _layers.LN_PRODUCER), ("FUSED_TOKENS", unet_addon_rawbox.FUSED_TOKENS))
 
-    def call(self, key, tensors, impl):
-        """tensors: flat list of tensors / None; impl(list) -> flat list of output tensors."""
+    def call(self, key, tensors, impl, alias_out=False):
+        """tensors: flat list of tensors / None; impl(list) -> flat list of output tensors.  alias_out: return views of
+        the graph's static output buffers instead of copies."""
         key = (key, tuple(None if t is None else (tuple(t.shape), t.dtype, tuple(t.stride())) for t in tensors))
+        if key in self.eager_only:
+            return impl(list(tensors))
         e = self.entries.get(key)
         if e is not None and e["epoch"] != _layers.CACHE_EPOCH[0]:
             e = None
@@ -91,12 +120,25 @@ class ForwardGraphs:
             self.entries.pop(key, None)
             while len(self.entries) >= max(1, self.MAX_ENTRIES):
                 self.entries.pop(next(iter(self.entries)))
-            e = self._capture(key, tensors, impl)
+            try:
+                e = self._capture(key, tensors, impl)
+            except Exception as exc:              # the eager path still works: remember, warn once, run it
+                self.eager_only.add(key)
+                import warnings
+                warnings.warn("dualdiff_amd: HIP-graph capture of a forward() failed (%s: %s); this call shape runs "
+                              "eagerly from now on" % (type(exc).__name__, str(exc)[:200]))
+                return impl(list(tensors))
+            self.captures += 1
         else:
             self.entries.pop(key)
         self.entries[key] = e                     # most recently used last
         e["graph"].replay()
-        return e["out"]
+        if alias_out:
+            return e["out"]
+        outs = e["out"]
+        own = [torch.empty_like(o) if torch.is_tensor(o) else o for o in outs]      # preserve_format: NHWC views stay NHWC
+        torch._foreach_copy_([o for o in own if torch.is_tensor(o)], [o for o in outs if torch.is_tensor(o)], non_blocking=True)
+        return own
 
     def _capture(self, key, tensors, impl):
         static, alias = [], []
@@ -108,12 +150,14 @@ class ForwardGraphs:
         s = torch.cuda.Stream()
         s.wait_stream(cur)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(s):
-            impl(static)                          # eager on the capture stream: tuning, packing, workspaces of this stream
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
-                out = impl(static)
-        cur.wait_stream(s)
+        try:
+            with torch.cuda.stream(s):
+                impl(static)                          # eager on the capture stream: tuning, packing, workspaces of this stream
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=s):
+                    out = impl(static)
+        finally:
+            cur.wait_stream(s)
         for o in out:
             if torch.is_tensor(o):
                 _STATIC_OUT[o.data_ptr()] = o
@@ -169,7 +213,32 @@ class ModelBase(nn.Module):
             self.__dict__["_fwd_graphs"].clear()
 
     # -- HIP graphs behind forward() -----------------------------------------------------------
-    graph_forward = True
+    graph_forward = True        # True: graphs, outputs copied out (safe default); "alias": graphs, outputs are views of
+                                # graph-owned buffers (valid until the next same-key call); False: eager launches
+
+    def _builtin_processors(self):
+        """True when every attention layer runs one of this package's own processors (which honour the capacity layout of
+        the context, layers.context_keys); a foreign callable may read all keys it is handed, so such a model gets exact
+        context lengths and eager launches."""
+        ok = self.__dict__.get("_fwd_builtin_procs")
+        if ok is None or ok[1] != _layers.CACHE_EPOCH[0]:    # Attention.set_processor bumps the epoch
+            from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor
+            builtin = (HIPAttnProcessor, Adapter_XFormersAttnProcessor, XFormersAttnProcessor)
+            procs = list(self.attn_processors.values())
+            ok = (all(type(p) in builtin for p in procs), _layers.CACHE_EPOCH[0],
+                  not any(type(p) is Adapter_XFormersAttnProcessor for p in procs))
+            self.__dict__["_fwd_builtin_procs"] = ok
+        return ok
+
+    def _varlen_ok(self):
+        """The context may be laid out at a bucket capacity with its real length in device memory: built-in processors
+        only, no box / class adapter (its context is [text | box | class] split by token counts), no sharding."""
+        if not VARLEN_CONTEXT:
+            return False
+        if getattr(self, "view_shard", None) is not None or getattr(self, "frame_shard", None) is not None:
+            return False
+        ok = self._builtin_processors()
+        return ok[0] and ok[2] and not getattr(self, "use_box_adapter", False)
 
     def _graphs(self):
         """The forward-graph cache, or None when this call must run eagerly: switched off, already inside a capture
@@ -179,13 +248,7 @@ class ModelBase(nn.Module):
             return None
         if getattr(self, "view_shard", None) is not None or getattr(self, "frame_shard", None) is not None:
             return None
-        ok = self.__dict__.get("_fwd_builtin_procs")
-        if ok is None or ok[1] != _layers.CACHE_EPOCH[0]:    # Attention.set_processor bumps the epoch
-            from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor
-            builtin = (HIPAttnProcessor, Adapter_XFormersAttnProcessor, XFormersAttnProcessor)
-            ok = (all(type(p) in builtin for p in self.attn_processors.values()), _layers.CACHE_EPOCH[0])
-            self.__dict__["_fwd_builtin_procs"] = ok
-        if not ok[0]:
+        if not self._builtin_processors()[0]:
             return None
         if self.__dict__.get("_fwd_graphs") is None:
             self.__dict__["_fwd_graphs"] = ForwardGraphs()

@@ -20,8 +20,24 @@ from .. import ops as O
 from .blocks import BasicMultiviewTransformerBlock
 from .layers import (BasicTransformerBlock, prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
                      TimestepEmbedding, Timesteps, UNetMidBlock2DCrossAttn, UpBlock2D, as_nchw_view,
-                     run_down_block, run_up_block, to_nhwc)
+                     run_down_block, run_up_block, to_nhwc, CTX_BASE, context_keys, ctx_capacity, lk_const)
 from .model_base import ModelBase
+
+
+def _at_capacity(ctx, cap):
+    """(m, lc, C) context -> (m, cap, C) with the same first lc tokens per instance.  A view of a capacity layout (the
+    tokens our ControlNet hands back: `buffer[:, :lc]`) is widened IN PLACE; anything else is copied into a zeroed
+    buffer.  The tokens past lc are never read by an attention (layers.context_keys); the K / V projection GEMM does
+    multiply them, so they must be memory this process owns."""
+    m, lc, c = ctx.shape
+    if lc == cap:
+        return ctx
+    if ctx.stride(2) == 1 and ctx.stride(1) == c and ctx.stride(0) == cap * c and \
+            (ctx.storage_offset() + m * cap * c) * ctx.element_size() <= ctx.untyped_storage().nbytes():
+        return ctx.as_strided((m, cap, c), ctx.stride())
+    buf = ctx.new_zeros((m, cap, c))
+    buf[:, :lc] = ctx
+    return buf
 
 
 @dataclass
@@ -225,23 +241,31 @@ class UNet2DConditionModelMultiview(ModelBase):
             raise RuntimeError("dualdiff_amd runs on the GPU only; got a %s tensor" % sample.device)
         m = sample.shape[0]
         n_down = None if down_block_additional_residuals is None else len(down_block_additional_residuals)
-        tensors = [sample, self._timesteps(timestep, m, sample.device), encoder_hidden_states]
+        # Context length (round 6): a context of CTX_BASE + N_box tokens is laid out at its bucket's capacity and its real
+        # length travels as one int32 in device memory (layers.context_keys) — one graph per bucket, not per box count
+        # (the ControlNet's tokens arrive as a view of such a layout and are read in place).
+        ctx, lk = encoder_hidden_states, None
+        if ctx.dim() == 3 and ctx.shape[1] >= CTX_BASE and self._varlen_ok():
+            lk = lk_const(ctx.shape[1], sample.device)
+            ctx = _at_capacity(ctx, ctx_capacity(ctx.shape[1]))
+        tensors = [sample, self._timesteps(timestep, m, sample.device), ctx, lk]
         tensors += list(down_block_additional_residuals or ()) + [mid_block_additional_residual]
         graphs = self._graphs()
         if graphs is None:
             out = self._forward_flat(tensors, n_down)[0]
         else:
-            # the noise prediction is small (4 channels): hand the caller its own copy, not a view of graph memory
-            out = graphs.call(("unet", n_down, graphs.flags(self)), tensors, lambda ts: self._forward_flat(ts, n_down))[0].clone()
+            # (the noise prediction is small, 4 channels: always the caller's own copy, never a view of graph memory)
+            out = graphs.call(("unet", n_down, graphs.flags(self)), tensors, lambda ts: self._forward_flat(ts, n_down))[0]
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)
 
     def _forward_flat(self, tensors, n_down):
-        """forward() on a flat tensor list [sample, t (m,) fp32, encoder_hidden_states, *down residuals, mid residual]
-        (what ForwardGraphs records): NCHW in, NCHW out, residuals NCHW-shaped (channels_last strides are zero-copy)."""
-        sample, t_f32, encoder_hidden_states = tensors[:3]
-        down = None if n_down is None else tensors[3:3 + n_down]
+        """forward() on a flat tensor list [sample, t (m,) fp32, encoder_hidden_states, real context length (int32 [1]) or
+        None, *down residuals, mid residual] (what ForwardGraphs records): NCHW in, NCHW out, residuals NCHW-shaped
+        (channels_last strides are zero-copy)."""
+        sample, t_f32, encoder_hidden_states, lk_dev = tensors[:4]
+        down = None if n_down is None else tensors[4:4 + n_down]
         mid = tensors[-1]
         dt = self.dtype
         x, m, h, w = to_nhwc(sample.to(dt))
@@ -254,7 +278,8 @@ class UNet2DConditionModelMultiview(ModelBase):
         ctx2d = ctx.reshape(m * lc, ctx.shape[2])
         if not ctx2d.is_contiguous():
             ctx2d = ctx2d.contiguous()
-        return [self.forward_nhwc(x, m, h, w, t_f32, ctx2d, lc, down_res, mid_res)]
+        with context_keys(ctx2d, lc, lk_dev):
+            return [self.forward_nhwc(x, m, h, w, t_f32, ctx2d, lc, down_res, mid_res)]
 
     def forward_nhwc(self, x, m, h, w, t_f32, ctx2d, lc, down_res=None, mid_res=None):
         """x: (m*h*w, 8) NHWC latents (4 channels zero-padded to 8); residuals: NHWC 2-D tensors in

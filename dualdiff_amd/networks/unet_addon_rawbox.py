@@ -27,7 +27,7 @@ from ..misc.common import load_module
 from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor  # noqa: F401
 from .embedder import get_embedder
 from .layers import (prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
-                     UNetMidBlock2DCrossAttn, as_nchw_view, run_down_block, to_nhwc)
+                     UNetMidBlock2DCrossAttn, as_nchw_view, box_capacity, context_keys, lk_const, run_down_block, to_nhwc)
 from .model_base import ModelBase
 from .output_cls import BEVControlNetOutput
 from .txt_con_fusion import txt_con_XFormersAttn, txt_con_XFormersAttn_plus
@@ -435,7 +435,20 @@ class BEVControlNetModel(ModelBase):
         t = t.to(device=sample.device, dtype=torch.float32).reshape(-1)
         t = t.repeat_interleave(m // t.numel()) if t.numel() != m else t          # :951-952
         box_keys = None if bboxes_3d_data is None else tuple(sorted(bboxes_3d_data))
-        tensors = [sample, t.contiguous(), camera_param, encoder_hidden_states, controlnet_cond]
+        # Context length (round 6): the number of boxes changes from sample to sample (the collate function pads them to
+        # the batch's maximum, dataset/utils.py:165-244, and the pipeline forwards that, pipeline_bev_controlnet.py:349-375).
+        # The boxes are padded HERE to their bucket's capacity with masked-out entries and the real context length goes
+        # down as one int32 in device memory: the cross-attentions read only the real tokens (layers.context_keys) and
+        # one recorded graph serves the whole bucket.  The tokens are handed back at their real length.
+        lc_true = lk = None
+        if bboxes_3d_data is not None and self._varlen_ok() and box_keys == ("bboxes", "classes", "masks"):
+            n_box = bboxes_3d_data["bboxes"].shape[2]
+            cap = box_capacity(n_box)
+            lc_true = 1 + encoder_hidden_states.shape[1] + n_box
+            if cap != n_box:
+                bboxes_3d_data = {k: _pad_boxes(v, cap) for k, v in bboxes_3d_data.items()}
+            lk = lk_const(lc_true, sample.device)
+        tensors = [sample, t.contiguous(), camera_param, encoder_hidden_states, controlnet_cond, lk]
         tensors += [] if box_keys is None else [bboxes_3d_data[k] for k in box_keys]
         scale = tuple(conditioning_scale) if isinstance(conditioning_scale, (list, tuple)) else float(conditioning_scale)
         graphs = self._graphs()
@@ -443,8 +456,11 @@ class BEVControlNetModel(ModelBase):
             outs = self._forward_flat(tensors, box_keys, scale, use_aug_text)
         else:
             outs = graphs.call(("controlnet", box_keys, scale, bool(use_aug_text), graphs.flags(self)), tensors,
-                               lambda ts: self._forward_flat(ts, box_keys, scale, use_aug_text))
+                               lambda ts: self._forward_flat(ts, box_keys, scale, use_aug_text),
+                               alias_out=self.graph_forward == "alias")
         down, mid, ctx = list(outs[:-2]), outs[-2], outs[-1]
+        if lc_true is not None and ctx.shape[1] != lc_true:
+            ctx = ctx[:, :lc_true]                      # the capacity layout stays inside; a view of its first tokens
         if not return_dict:
             return down, mid, ctx
         return BEVControlNetOutput(down_block_res_samples=down, mid_block_res_sample=mid,
@@ -452,10 +468,11 @@ class BEVControlNetModel(ModelBase):
 
     def _forward_flat(self, tensors, box_keys, conditioning_scale, use_aug_text):
         """forward() on a flat tensor list [sample (b, n, 4, h, w), t (b*n,) fp32, camera_param, encoder_hidden_states,
-        controlnet_cond, *bboxes_3d_data values in key order] (what ForwardGraphs records).  Returns the 12 down
-        residuals + the mid residual as logical-NCHW views of the NHWC buffers, then the tokens with the camera token."""
-        sample, t, camera_param, encoder_hidden_states, controlnet_cond = tensors[:5]
-        bboxes_3d_data = None if box_keys is None else dict(zip(box_keys, tensors[5:]))
+        controlnet_cond, real context length (int32 [1]) or None, *bboxes_3d_data values in key order] (what
+        ForwardGraphs records).  Returns the 12 down residuals + the mid residual as logical-NCHW views of the NHWC
+        buffers, then the tokens with the camera token (at the capacity length when a real length was given)."""
+        sample, t, camera_param, encoder_hidden_states, controlnet_cond, lk_dev = tensors[:6]
+        bboxes_3d_data = None if box_keys is None else dict(zip(box_keys, tensors[6:]))
         dt = self.dtype
         b, n_cam = sample.shape[:2]
         prep = self.prepare_condition(camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond,
@@ -464,8 +481,17 @@ class BEVControlNetModel(ModelBase):
         if x.shape[1] != self.conv_in.cin_pad:
             x = torch.nn.functional.pad(x, (0, self.conv_in.cin_pad - x.shape[1]))
         scale = list(conditioning_scale) if isinstance(conditioning_scale, tuple) else conditioning_scale
-        outs = self.forward_nhwc(x, m, h, w, t, prep, scale)
+        with context_keys(prep["ctx"], prep["lc"], lk_dev):
+            outs = self.forward_nhwc(x, m, h, w, t, prep, scale)
         return [as_nchw_view(o, m, oh, ow) for o, oh, ow in outs] + [prep["ctx"]]
+
+
+def _pad_boxes(v, cap):
+    """(b, n, N, ...) box tensor -> (b, n, cap, ...), the new entries zero (masks: False — masked-out boxes)."""
+    out = v.new_zeros((v.shape[0], v.shape[1], cap) + tuple(v.shape[3:]))
+    if v.shape[2]:
+        out[:, :, :v.shape[2]] = v
+    return out
 
 
 # token preparation as four launches (csrc/tokens.hip) instead of ~20 tensor ops per branch; False = the tensor-op chain

@@ -702,7 +702,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_map=None,
               out=None, accumulate=False, variant=0, q_prescaled=False, seq_strides=None,
-              out_seq_strides=None, kv_batch_map2=None, kv_seq_strides=None):
+              out_seq_strides=None, kv_batch_map2=None, kv_seq_strides=None, lk_dev=None):
     """softmax(scale * q k^T) v per (batch, head).
 
     q / k / v may also be HEAD-MAJOR 3-D tensors (heads, rows, head_dim) — slices of a
@@ -717,9 +717,15 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     pitch), out_seq_strides likewise for `out` (default: the same): the sequence runs over rows `row_stride`
     apart and consecutive batches start `batch_stride` apart — attention ALONG ANOTHER AXIS of a (frames, tokens, C) activation without a transpose
     (temporal attention: row_stride = tokens_per_frame * C, batch_stride = C).  kv_seq_strides: the same pair for k / v
-    when they live in another buffer than q (frame-split temporal attention: local queries, gathered keys)."""
+    when they live in another buffer than q (frame-split temporal attention: local queries, gathered keys).
+
+    lk_dev: int32 device tensor [1] with the number of keys every batch entry REALLY has; `lk` is then the capacity the
+    K / V rows were laid out for (dd_attn_desc.lk_dev: the kernel reads the count at its start, so a recorded HIP graph
+    serves every context length up to the capacity)."""
     lib = _native.load()
-    _need_gpu(q, k, v, out, kv_batch_map, kv_batch_map2)
+    _need_gpu(q, k, v, out, kv_batch_map, kv_batch_map2, lk_dev)
+    if lk_dev is not None and (lk_dev.dtype != torch.int32 or lk_dev.numel() < 1):
+        raise TypeError("lk_dev must be an int32 device tensor")
     if kv_batch_map2 is not None and (kv_batch_map is None or seq_strides is not None):
         raise ValueError("kv_batch_map2 needs kv_batch_map and no seq_strides")
     if kv_seq_strides is not None and seq_strides is None:
@@ -768,6 +774,7 @@ def attention(q, k, v, batch, lq, lk, heads, head_dim, scale=None, *, kv_batch_m
     d.accumulate = int(accumulate)
     d.dtype = _dt(q)
     d.variant = variant
+    d.lk_dev = lk_dev.data_ptr() if lk_dev is not None else None
     if seq_strides is not None and batch * heads > 65535:
         # the launcher's grid covers at most 65535 (batch, head) pairs: walk the batch in chunks
         es, per = q.element_size(), 65535 // heads
@@ -829,15 +836,18 @@ def _xpacked(w):
     return w if w.dim() == 1 and w.numel() == 320 * 320 else xattn_pack_weight(w)
 
 
-def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=None, ln_out=None, out=None):
+def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=None, ln_out=None, out=None, lk_dev=None):
     """Fused q-projection -> attention over the lk context keys of each view-instance -> out-projection + bias +
     residual, one launch (include/dualdiff_hip.h: dd_xattn320).  x: (instances * rows_per_inst, 320); k / v: either
     (instances * lk, >= 320) row-strided 2-D views (column slices of a wider projection) or HEAD-MAJOR 3-D tensors
     (8, instances * lk, 40) — slices of a `gemm(..., head_major=(40, 0, 1.0))` result, the form the kernel streams
     fastest; wq / wo: the packed copies of the (320, 320) Linear weights (xattn_pack_weight; layers.Linear.wx) or the raw weights; ln_out = (gamma, beta, eps):
-    LayerNorm(out) comes back as `out._ln_out`."""
+    LayerNorm(out) comes back as `out._ln_out`.  lk_dev: as in attention() — the real key count in device memory, `lk`
+    the capacity of the K / V layout."""
     lib = _native.load()
-    _need_gpu(x, wq, wo, bo, k, v, res, out)
+    _need_gpu(x, wq, wo, bo, k, v, res, out, lk_dev)
+    if lk_dev is not None and (lk_dev.dtype != torch.int32 or lk_dev.numel() < 1):
+        raise TypeError("lk_dev must be an int32 device tensor")
     x = _rows2d(x)
     rows = instances * rows_per_inst
     if x.shape != (rows, 320):
@@ -875,6 +885,7 @@ def xattn320(x, wq, wo, bo, k, v, instances, rows_per_inst, lk, scale, *, res=No
     d.out, d.ldo = out.data_ptr(), out.stride(0)
     d.instances, d.rows_per_inst, d.lk = int(instances), int(rows_per_inst), int(lk)
     d.channels, d.heads, d.scale, d.dtype = 320, 8, float(scale), _dt(x)
+    d.lk_dev = lk_dev.data_ptr() if lk_dev is not None else None
     second = None
     if ln_out is not None:
         g_, b_, eps_ = ln_out

@@ -31,9 +31,13 @@ extern "C" {
  * 3 (round 5): what was measured and never dispatched is gone — dd_gemm_desc lost ln_gamma / ln_beta / w_scale (row-panel
  * family), splitk_inkernel, prefetch / prefetch_bytes; dd_attn_desc.variant takes 0 only; the cooperative GroupNorm
  * entry points (dd_groupnorm_is_coop / _set_coop) are removed and its workspace carries no barrier state.
+ * 4 (round 6): dd_attn_desc / dd_xattn_desc gained lk_dev — the key count of a cross-attention read from DEVICE memory,
+ * so that one recorded HIP graph serves every context length (78 + N_box tokens: the reference's collate function pads
+ * the boxes to the batch's maximum, dataset/utils.py:165-244, so the length changes from sample to sample) up to the
+ * capacity it was recorded at.
  * A binding must check BOTH the version and the descriptor sizes (dd_desc_size) before the first launch: a stale
  * pair would read past the caller's struct. */
-#define DD_ABI_VERSION 3
+#define DD_ABI_VERSION 4
 
 enum { DD_F16 = 0, DD_BF16 = 1 };
 
@@ -240,6 +244,11 @@ typedef struct dd_attn_desc {
    * — two softmaxes with their own normalisation, summed in fp32 and rounded once.  Needs kv_batch_map and the default
    * variant (0); NULL = single attention. */
   const int32_t* kv_batch_map2;
+  /* NULL, or a 4-byte-aligned DEVICE pointer to the number of keys every batch entry really has: the kernel reads it at
+   * its start (clamped to [1, lk]) and `lk` is then only the CAPACITY — it sizes the strides the caller built and selects
+   * the instantiation; keys lk_dev[0] .. lk-1 are never read.  Same arithmetic as a launch with lk = lk_dev[0] and the
+   * same strides: bit-identical results. */
+  const int32_t* lk_dev;
 } dd_attn_desc;
 
 int dd_attention(const dd_attn_desc* d, dd_stream_t stream);
@@ -277,6 +286,7 @@ typedef struct dd_xattn_desc {
   int32_t dtype;
   void* ln_out; int64_t ld_ln_out;         /* NULL = off */
   const void* ln_gamma; const void* ln_beta; float ln_eps;
+  const int32_t* lk_dev;                   /* as dd_attn_desc.lk_dev: keys per instance from device memory, lk = capacity */
 } dd_xattn_desc;
 
 int dd_xattn320(const dd_xattn_desc* d, dd_stream_t stream);

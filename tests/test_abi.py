@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "%s declared in the header but not exported" % name
     assert sorted(_native.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert lib.dd_abi_version() == _native.ABI_VERSION == 3
+    assert lib.dd_abi_version() == _native.ABI_VERSION == 4
     import ctypes
     for which, st in enumerate((_native.GemmDesc, _native.AttnDesc, _native.XAttnDesc, _native.Gemm8Desc,
                               _native.BoxTokensDesc)):

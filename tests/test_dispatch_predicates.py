@@ -136,3 +136,28 @@ def test_gemm_plans_exist_for_every_level_of_every_resolution():
                     nm = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
                     assert nm.startswith("dd_gemm3_kernel"), (tile, nm)
                 d.tile = 0
+
+
+def test_layernorm_fold_plans_without_a_tuned_tile():
+    """with `ln_colsum` set and no tile named (DD_AUTOTUNE=0, or an untuned shape first met inside a capture)
+    the planner maps the heuristic's register-staged pick onto its LDS-DMA twin BY SHAPE; the fixed id table it used
+    pointed at two tiles round 5 had removed, so 64x64 / 128x64 picks returned DD_ERR_UNSUPPORTED."""
+    lib = _native.load()
+    for rows in (96, 336, 1092, 4200, 16800, 67200):
+        for k in (320, 640, 1280):
+            for n in (k, 3 * k):
+                d = _native.GemmDesc()
+                d.a = d.w = d.out = d.ln_colsum = d.ln_bias = 4096
+                d.rows, d.n, d.k, d.k1 = rows, n, k, k
+                d.lda, d.ldc = k, n
+                d.alpha, d.ln_eps = 1.0, 1e-5
+                d.dtype, d.tile = 0, 0
+                name = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
+                assert name.startswith("dd_gemm2_kernel<"), (rows, n, k, name)
+            g = _native.GemmDesc()                               # the GEGLU projection (8C wide, gate in the epilogue)
+            g.a = g.w = g.out = g.ln_colsum = g.ln_bias = 4096
+            g.rows, g.n, g.k, g.k1 = rows, 4 * k, k, k
+            g.lda, g.ldc = k, 4 * k
+            g.alpha, g.ln_eps, g.epilogue = 1.0, 1e-5, 1
+            name = lib.dd_gemm_kernel_name(ctypes.byref(g)).decode()
+            assert name.startswith("dd_gemm2_kernel<") and name.split(">")[0].endswith("true"), (rows, k, name)

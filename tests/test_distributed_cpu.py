@@ -229,6 +229,29 @@ def test_bench_gpus_flag_self_launches_n_ranks(n):
     assert out["n_gpus"] == n and out["requested_gpus"] == n
     assert out["plumbing_check"] is True and out["value"] is None
     assert out["slowest_rank_seconds"] == float(n)          # max over ranks of (1 + rank)
+    # for N > 1 the line shows that the collective backend saw N ranks (all-reduce of the rank ids);
+    # item 6: it lists the DD_* switches of the process
+    if n > 1:
+        assert out["collective"] == {"backend": "gloo", "world_size": n, "rank_sum": n * (n - 1) // 2, "rank_sum_check": True}
+    else:
+        assert "collective" not in out
+    assert out["env"] == []
+
+
+def test_bench_lists_dd_switches_and_refuses_an_alternative_library():
+    """DD_* environment switches change what a run measures, so the line lists them; DD_HIP_LIB (another
+    build of the C-ABI library) is refused outright unless --allow-alt-lib says the A/B is intended."""
+    import subprocess
+    import sys
+    out = _bench_line(["--gpus", "1", "--plumbing-check"], env={"DD_PERSIST": "0", "DD_FUSED_TOKENS": "1"})
+    assert out["env"] == ["DD_FUSED_TOKENS=1", "DD_PERSIST=0"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, DD_HIP_LIB="/tmp/some_other_lib.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--plumbing-check"],
+                       capture_output=True, text=True, timeout=300, env=e, cwd=root)
+    assert r.returncode != 0 and "--allow-alt-lib" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    ok = _bench_line(["--gpus", "1", "--plumbing-check", "--allow-alt-lib"], env={"DD_HIP_LIB": "/tmp/some_other_lib.so"})
+    assert ok["env"] == ["DD_HIP_LIB=/tmp/some_other_lib.so"]
 
 
 def test_bench_strong_scaling_leg_is_a_child_job_in_the_same_line():

@@ -292,6 +292,16 @@ def test_fold_lora_key_validation_and_alpha():
     with pytest.raises(KeyError):
         fold_lora_(net5, lora, 0.5, network_alphas={"unet.attn7.processor.to_q_lora.down.weight.alpha": 8.0})
     assert torch.equal(net5.attn1.to_q.weight, w0)
+    # the loader hands over the WHOLE mapping — text-encoder alphas are someone else's and are skipped, and
+    # 'to_out.0[.lora...]' stems (the Linear inside the ModuleList) name the out-projection
+    net6 = seeded_init_(Holder(), 5)
+    wo0 = net6.attn1.to_out[0].weight.detach().clone()
+    dn_o, up_o = lora["attn1.processor.to_out_lora.down.weight"], lora["attn1.processor.to_out_lora.up.weight"]
+    fold_lora_(net6, lora, 0.5, network_alphas={"text_encoder.text_model.encoder.layers.0.self_attn.q_proj.alpha": 3.0,
+                                                "unet.attn1.to_out.0.lora.down.weight.alpha": 8.0,
+                                                "unet.attn1.to_q.alpha": 8.0})
+    assert torch.allclose(net6.attn1.to_q.weight, w0 + 0.5 * (8.0 / 4) * up @ down, atol=1e-6)
+    assert torch.allclose(net6.attn1.to_out[0].weight, wo0 + 0.5 * (8.0 / 4) * up_o @ dn_o, atol=1e-6)
 
 
 def _synthetic_full_report(n_classes=40):
@@ -334,7 +344,13 @@ def _synthetic_full_report(n_classes=40):
             "unipc20": {"value": 88.1, "unit": "steps/s", "ms_per_step": 11.35, "ms_per_20_step_sample": 227.0,
                         "outputs_finite": True, "sampler": "u" * 120},
             "dropin": {"value": 77.2, "unit": "steps/s", "ms_per_step": 12.95, "forward_graphs": [1, 1, 1], "vs_fused": 0.87,
-                       "outputs_finite": True, "loop": "l" * 200}}
+                       "outputs_finite": True, "loop": "l" * 200},
+            # round 6
+            "dropin_varlen": {"value": 71.3, "unit": "steps/s", "ms_per_step": 14.02, "box_counts": [20, 7, 13, 20, 31, 7],
+                              "steps_per_sample": 20, "captures": [1, 1, 1], "vs_dropin": 0.924, "outputs_finite": True,
+                              "loop": "v" * 200},
+            "env": ["DD_PERSIST=0"],
+            "collective": {"backend": "nccl", "world_size": 8, "rank_sum": 28, "rank_sum_check": True}}
 
 
 def test_bench_line_stays_parseable_and_short():
@@ -362,9 +378,13 @@ def test_bench_line_stays_parseable_and_short():
     assert back["dropin"]["vs_fused"] == 0.87 and "loop" not in back["dropin"]
     assert back["unipc20"]["ms_per_20_step_sample"] == 227.0 and "sampler" not in back["unipc20"]
     assert back["batched"]["roofline"]["frac"] == 0.3605 and "roofline_classes" not in back["batched"]
+    # round 6: the changing-box-count leg, the DD_* switches that were set, and the N > 1 collective evidence
+    assert back["dropin_varlen"]["vs_dropin"] == 0.924 and back["dropin_varlen"]["captures"] == [1, 1, 1] and "loop" not in back["dropin_varlen"]
+    assert back["env"] == ["DD_PERSIST=0"] and back["collective"]["rank_sum_check"] is True
     # degenerate inputs: no roofline / no CPU leg (N > 1 ranks), and an absurdly long free-text field still fits
     bare = dict(full, roofline=None, cpu_baseline=None)
     assert len(json.dumps(bench.compact_line(bare))) < 4096
+    assert bench.compact_line({k: v for k, v in full.items() if k != "env"})["env"] == []
     fat = _synthetic_full_report(40)
     fat["strong_scaling"]["error"] = "e" * 6000
     fat["config"]["workload"] = "w" * 3000
