@@ -50,6 +50,8 @@ struct GemmParams {
   float inv_hw, inv_wout, inv_rpi;       // 1 / (hout*wout), 1 / wout, 1 / rows_per_inst for dd_fdiv
   void* ln_out; int64_t ld_ln_out;       // LayerNorm EMITTED by the epilogue of the 80x320 tile (second output)
   const void* lno_gamma; const void* lno_beta;
+  float inv_tiles_n, inv_hm_d;           // dd_gemm4_kernel: 1 / tiles_n, 1 / hm_d for dd_fdiv
+  uint32_t ln_out_bytes;                 // ... extent of ln_out for its buffer stores
 };
 
 // n / d for 0 <= n < 2^22 (host-checked: rows) and the host-side inv = 1.0f / d: (n + 0.5) * inv is never within
@@ -200,7 +202,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
         }
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = h[e] * dd_gelu_erf_f(g[e]);
+        for (int e = 0; e < 8; ++e) v[e] = dd_geglu_f(h[e], g[e]);
         dd_st16(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + col, dd_pack8<T>(v));
       }
     }
@@ -1404,6 +1406,558 @@ void dd_gemm3_kernel(const GemmParams p) {
 }
 
 // =============================================================================================
+// Kernel family 2q (round 6): dd_gemm3's pipelined K-step as a PERSISTENT loop over tiles.
+//
+// dd_gemm3_kernel runs one tile per workgroup: a launch of G generations of tiles pays, G times over, the ring fill
+// (every CU pulls its first stages at once), the drain, the table build and an epilogue whose stores nothing overlaps
+// (profiles/r05_gemm3_bound.txt: with BOTH the LDS-DMAs and the MFMAs removed 58-71 % of the K = 320 / 640 launches is still
+// there).  Here a workgroup walks the tiles lin, lin + gridDim.x, ... as ONE pipeline of K-steps: the ring never drains
+// between tiles — the stages of tile i+1 are issued under the last D K-steps of tile i, its stage-0 fragments are read
+// under tile i's last MFMAs — and the epilogue of tile i (its operand loads issued A K-steps ahead, its stores) runs with
+// D stages of tile i+1 in flight.  The stated obstacle — loads, stores and LDS-DMAs share ONE in-order vmcnt queue — is
+// handled by COUNTING: every epilogue issues a fixed number of vector-memory operations (buffer loads / stores whose
+// absent operands and out-of-range rows are descriptor range checks, never predication), and the wait in front of a
+// K-step allows, besides the younger stages, exactly those epilogue operations that were issued AFTER the stage it
+// certifies (two scalar ages, counted in issued stages).  Same arithmetic in the same order per accumulator as
+// dd_gemm3_kernel / dd_gemm2_kernel -> bit-identical results.
+// Dense, no split-K, K >= D steps (host-checked); epilogues: plain (bias, alpha, residual, SiLU, accumulate, head-major
+// planes), GEGLU, and the LayerNorm-emitting 80 x 320 tile.
+// =============================================================================================
+// A 16-byte buffer load the COMPILER DOES NOT TRACK (inline asm): its result is consumed A + 1 K-steps later, behind a
+// loop whose LDS-DMAs share the vmcnt queue — for a load it tracks, the compiler's own wait in front of the first use can
+// only be vmcnt(0) there (it cannot count the loop's iterations), which would drain the ring once per tile.  The caller
+// waits by count (wait_loads) and pins the registers to that wait (dd_pin).
+__device__ __forceinline__ u32x4 dd_rsrc_words(const void* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ u32x4 dd_bload16(u32x4 rsrc, uint32_t voff, uint32_t soff = 0) {
+  u32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return v;
+}
+__device__ __forceinline__ void dd_pin(u32x4& v) { asm volatile("" : "+v"(v)); }   // uses of v stay behind this point
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {          // vmcnt(min(N, 63)): waiting for MORE than asked is always safe
+  wait_vmcnt<(N > 63 ? 63 : N)>();
+}
+
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, bool GEGLU>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (gemm3_min_waves<WAVES_M, WAVES_N>()))
+void dd_gemm4_kernel(const GemmParams p) {
+  using V8 = typename dd_vec<T>::v8;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 16;
+  constexpr int BN = WAVES_N * TN * 16;
+  constexpr int BN_OUT = GEGLU ? BN / 2 : BN;
+  constexpr int XI = BM / 8 / NW;
+  constexpr int WI = BN / 8 / NW;
+  constexpr int LPS = XI + WI;
+  constexpr int STAGE = (BM + BN) * BK;
+  constexpr bool TIGHT = NSTAGE <= 3;
+  constexpr int D = TIGHT ? NSTAGE : NSTAGE - 1;
+  constexpr bool LNOUT = !GEGLU && WAVES_M == 1 && WAVES_N == 10 && TM == 5 && TN == 2;   // tile 74: ALWAYS emits LayerNorm(out)
+  constexpr int NG = GEGLU ? TN / 4 : TN / 2;                // 8-column output groups per lane
+  constexpr bool PRE_ACC = !GEGLU && !LNOUT && TM * NG <= 4; // accumulate target preloaded (else: host keeps such calls off this kernel)
+  // epilogue operand loads / stores per lane and tile — FIXED counts (see the header)
+  constexpr int EL = LNOUT ? 3 + TM : GEGLU ? 2 * NG : NG + TM * NG + (PRE_ACC ? TM * NG : 0);
+  constexpr int ES = LNOUT ? 2 * TM : TM * NG;
+  // the operand loads go out A K-steps before the tile's last one and stay in registers until the epilogue.  LATE (the
+  // 10-wave tiles: 168 registers per wave, no room for them beside the accumulators and two fragment sets): the loads go
+  // out IN the epilogue and it waits for everything in flight — the stages of the next tile keep landing meanwhile.
+  constexpr bool LATE = NW > 8;
+  constexpr int A = LATE ? 0 : D - 1;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
+  static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 8 && D >= 3, "NSTAGE");
+  static_assert((D - 2) * LPS + EL + ES <= 63 && (A + 1) * LPS <= 63, "vmcnt is a 6-bit counter");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* ring = reinterpret_cast<T*>(smem);
+  __shared__ float s_ln[LNOUT ? NW * BM : 1];               // LayerNorm partials: NOT in the ring (it is never idle here)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int G = (int)gridDim.x;
+  const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;      // >= 1: the grid never exceeds the tile count
+  const int nk = p.k / BK;                                           // split == 1, K % 64 == 0 (host-checked)
+  const int T_ALL = my_tiles * nk;                                   // K-steps of this workgroup
+
+  const int lrow = lane >> 3;
+  const int lc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const uint32_t lcb = (uint32_t)lc * 16u;
+
+  // ---- issue side: the tile whose stages are being issued, its tables, its K cursor ---------------------------------
+  int ilin = blockIdx.x;
+  uint32_t wv[WI], xe[XI];
+  int i_m0 = 0;
+  auto make_wv = [&](const int bn0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      const int R = (j * NW + wave) * 8 + lrow;
+      const int wvi = R / (TN * 16);
+      const int rho = R % (TN * 16);
+      const int tn = rho >> 4, r = rho & 15;
+      int n_glob;
+      if (GEGLU) {
+        constexpr int TH = TN / 2;
+        const int t = tn % TH;
+        const int col = bn0 + wvi * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
+        n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
+      } else {
+        const int col = bn0 + wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
+        n_glob = (col < p.n) ? col : -1;
+      }
+      wv[j] = n_glob >= 0 ? (uint32_t)n_glob * (uint32_t)p.k * 2u + lcb : DD_OOB;
+    }
+  };
+  auto make_xe = [&](const int64_t ld) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int r = i_m0 + (j * NW + wave) * 8 + lrow;
+      xe[j] = r < p.rows ? (uint32_t)r * (uint32_t)ld * 2u + lcb : DD_OOB;
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+  int ik0 = 0, islot = 0, kbase = 0;
+  int seam_k = p.a2 ? p.k1 : 0x7fffffff;
+  __amdgpu_buffer_rsrc_t rs_x = rs_a;
+  auto issue_tile = [&](const int lin) __attribute__((always_inline)) {     // point the issue side at tile `lin`
+    const int t = xcd_remap(lin, ntiles);
+    const int tm_i = dd_fdiv(t, p.inv_tiles_n);
+    i_m0 = tm_i * BM;
+    make_wv((t - tm_i * p.tiles_n) * BN_OUT);
+    make_xe(p.lda);
+    rs_x = rs_a;
+    kbase = 0;
+    seam_k = p.a2 ? p.k1 : 0x7fffffff;
+    ik0 = 0;
+  };
+  auto seam = [&]() __attribute__((always_inline)) {
+    if (ik0 >= seam_k) {
+      make_xe(p.lda2);
+      rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a2), 0, p.a2_bytes, 0x00020000);
+      kbase = p.k1;
+      seam_k = 0x7fffffff;
+    }
+  };
+  auto next_issue_tile = [&]() __attribute__((always_inline)) {
+    if (ik0 >= p.k && ilin + G < ntiles) { ilin += G; issue_tile(ilin); }
+  };
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    T* xs = ring + islot * STAGE;
+    T* ws = xs + BM * BK;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], (uint32_t)ik0 * 2u, ws + (j * NW + wave) * 8 * BK);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) bdma16(rs_x, xe[j], (uint32_t)(ik0 - kbase) * 2u, xs + (j * NW + wave) * 8 * BK);
+    ik0 += BK;
+    islot = islot + 1 == NSTAGE ? 0 : islot + 1;
+  };
+  issue_tile(ilin);
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  int clin = blockIdx.x;
+  int block_m0, block_n0;
+  auto compute_tile = [&](const int lin) __attribute__((always_inline)) {
+    const int t = xcd_remap(lin, ntiles);
+    const int tm_i = dd_fdiv(t, p.inv_tiles_n);
+    block_m0 = tm_i * BM;
+    block_n0 = (t - tm_i * p.tiles_n) * BN_OUT;
+  };
+  compute_tile(clin);
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fswz = (lane >> 1) & 7;
+  const int fchunk = lane >> 4;
+  const int cofs0 = ((fchunk + 0) ^ fswz) << 3, cofs1 = ((fchunk + 4) ^ fswz) << 3;
+  const T* xbase = ring + (wave_m * TM * 16 + frow) * BK;
+  const T* wbase = ring + BM * BK + (wave_n * TN * 16 + frow) * BK;
+
+  // prologue: stages 0 and 1 first, the rest behind the first fragment reads (as dd_gemm3_kernel); T_ALL >= nk >= D
+#pragma unroll
+  for (int s0 = 0; s0 < 2; ++s0) { issue_next(); seam(); next_issue_tile(); }
+
+  V8 wf[2][TN], xf[2][TM];
+  int rslot = 0;
+  auto read_half = [&](auto ks_c) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_c)::value;
+    const int cofs = ks ? cofs1 : cofs0;
+    const T* ws = wbase + rslot * STAGE + cofs;
+    const T* xs = xbase + rslot * STAGE + cofs;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[ks][i] = dd_as_v8<T>(dd_ld16(ws + i * 16 * BK));
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[ks][j] = dd_as_v8<T>(dd_ld16(xs + j * 16 * BK));
+  };
+  auto mfma_half = [&](auto ks_c) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  constexpr int NMF = TN * TM, NRD = TN + TM;
+
+  wait_vmcnt<LPS>();                               // stage 0 landed (stage 1 may be in flight)
+  __builtin_amdgcn_s_barrier();
+  read_half(K0{});
+  read_half(K1{});
+  rslot = 1;
+#pragma unroll
+  for (int s0 = 2; s0 < D; ++s0) { issue_next(); seam(); next_issue_tile(); }
+
+  // READ = false: the last K-step of a tile — the next tile's stage-0 fragments are read AFTER the epilogue instead of
+  // under these MFMAs (exposed once per tile, ~0.1 us), so that the epilogue does not run with two fragment sets live
+  // (with them the 10-wave tiles spilled fragments INSIDE the K loop, and a scratch reload waits vmcnt(0): the whole ring)
+  auto steady = [&](auto issue_c, auto read_c) __attribute__((always_inline)) {
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    constexpr bool READ = decltype(read_c)::value;
+    const T* wp0 = wbase + rslot * STAGE + cofs0;
+    const T* xp0 = xbase + rslot * STAGE + cofs0;
+    const T* wp1 = wbase + rslot * STAGE + cofs1;
+    const T* xp1 = xbase + rslot * STAGE + cofs1;
+    T* xs = ring + islot * STAGE;
+    T* ws = xs + BM * BK;
+    const uint32_t so_w = (uint32_t)ik0 * 2u, so_x = (uint32_t)(ik0 - kbase) * 2u;
+    auto dma = [&](const int u) __attribute__((always_inline)) {
+      if (u < WI) bdma16(rs_w, wv[u], so_w, ws + (u * NW + wave) * 8 * BK);
+      else bdma16(rs_x, xe[u - WI], so_x, xs + ((u - WI) * NW + wave) * 8 * BK);
+    };
+    auto rd = [&](const int ks, const int u) __attribute__((always_inline)) {
+      if (u < TN) wf[ks][u] = dd_as_v8<T>(dd_ld16((ks ? wp1 : wp0) + u * 16 * BK));
+      else xf[ks][u - TN] = dd_as_v8<T>(dd_ld16((ks ? xp1 : xp0) + (u - TN) * 16 * BK));
+    };
+    auto mf = [&](const int ks, const int u) __attribute__((always_inline)) {
+      const int i = u / TM, j = u % TM;
+      acc[i][j] = dd_mfma16(wf[ks][i], xf[ks][j], acc[i][j]);
+    };
+    constexpr int NDM = ISSUE ? LPS : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int u = 0; u < (NMF > NDM ? NMF : NDM); ++u) {
+      if (u < NMF) mf(0, u);
+      if (u < NDM) dma(u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < (NMF > NRD ? NMF : NRD); ++u) {
+      if (READ && u < NRD) rd(0, u);
+      if (u < NMF) mf(1, u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (READ) {
+#pragma unroll
+      for (int u = 0; u < NRD; ++u) rd(1, u);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (ISSUE) {
+      ik0 += BK;
+      islot = islot + 1 == NSTAGE ? 0 : islot + 1;
+    }
+    if constexpr (READ) rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
+  };
+
+  // ---- epilogue state: operand registers and store offsets of the tile being multiplied ------------------------------
+  const int q4 = lane >> 4, c16 = lane & 15;
+  u32x4 pb[LNOUT ? 3 : (GEGLU ? 2 * NG : NG)];               // bias (GEGLU: h then gate; LN: bias, gamma, beta)
+  u32x4 pr[(GEGLU ? 1 : TM)][(GEGLU || LNOUT) ? 1 : NG];     // residual
+  u32x4 pa[PRE_ACC ? TM : 1][PRE_ACC ? NG : 1];              // accumulate target
+  uint32_t off_o[TM][LNOUT ? 1 : NG];                        // byte offset of the 16-byte store, or DD_OOB
+  uint32_t off_l[LNOUT ? TM : 1];                            // LN: offset into ln_out
+  float hmf[(GEGLU || LNOUT) ? 1 : NG];                      // head-major planes: the Q planes' factor
+  const uint32_t e_bias = p.bias ? (uint32_t)(GEGLU ? 2 * p.n : p.n) * 2u : 0u;
+  const u32x4 rs_b = dd_rsrc_words(p.bias, e_bias);
+  const u32x4 rs_r = dd_rsrc_words(p.res, p.res ? p.res_bytes : 0u);
+  const u32x4 rs_ac = dd_rsrc_words(p.out, p.accumulate ? p.out_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  auto epi_loads = [&]() __attribute__((always_inline)) {    // EL buffer loads, whatever the operands (absent: extent 0 -> zeros)
+    const int erow0 = block_m0 + wave_m * (TM * 16) + c16;
+    if constexpr (LNOUT) {
+      const int col = wave_n * 32 + q4 * 8;
+      const u32x4 rs_g = dd_rsrc_words(p.lno_gamma, 640u);
+      const u32x4 rs_be = dd_rsrc_words(p.lno_beta, 640u);
+      pb[0] = dd_bload16(rs_b, (uint32_t)col * 2u);
+      pb[1] = dd_bload16(rs_g, (uint32_t)col * 2u);
+      pb[2] = dd_bload16(rs_be, (uint32_t)col * 2u);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = erow0 + tm * 16;
+        const bool ok = row < p.rows;
+        off_o[tm][0] = ok ? ((uint32_t)row * (uint32_t)p.ldc + (uint32_t)col) * 2u : DD_OOB;
+        off_l[tm] = ok ? ((uint32_t)row * (uint32_t)p.ld_ln_out + (uint32_t)col) * 2u : DD_OOB;
+        pr[tm][0] = dd_bload16(rs_r, ok ? ((uint32_t)row * (uint32_t)p.ldres + (uint32_t)col) * 2u : DD_OOB);
+      }
+    } else if constexpr (GEGLU) {
+      constexpr int TH = TN / 2;
+      const int ecol0 = block_n0 + wave_n * (TH * 16) + q4 * (4 * TH);
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
+        const int col = ecol0 + g8 * 8;
+        const uint32_t ob = col < p.n ? (uint32_t)col * 2u : DD_OOB;
+        pb[g8] = dd_bload16(rs_b, ob);
+        pb[NG + g8] = dd_bload16(rs_b, ob, (uint32_t)p.n * 2u);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = erow0 + tm * 16;
+          off_o[tm][g8] = (row < p.rows && col < p.n) ? ((uint32_t)row * (uint32_t)p.ldc + (uint32_t)col) * 2u : DD_OOB;
+        }
+      }
+    } else {
+      const int ecol0 = block_n0 + wave_n * (TN * 16) + q4 * (4 * TN);
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
+        const int col = ecol0 + g8 * 8;
+        pb[g8] = dd_bload16(rs_b, col < p.n ? (uint32_t)col * 2u : DD_OOB);
+        int plane = 0;
+        hmf[g8] = 1.0f;
+        if (p.hm_d) {                                          // one [rows][D] plane per head; 8 columns never straddle a plane
+          plane = dd_fdiv(col, p.inv_hm_d);
+          if (plane < p.hm_planes) hmf[g8] = p.hm_scale;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = erow0 + tm * 16;
+          const bool ok = row < p.rows && col < p.n;
+          uint32_t oo = ((uint32_t)row * (uint32_t)p.ldc + (uint32_t)col) * 2u;
+          if (p.hm_d) oo = (((uint32_t)plane * (uint32_t)p.rows + (uint32_t)row) * (uint32_t)p.hm_d + (uint32_t)(col - plane * p.hm_d)) * 2u;
+          off_o[tm][g8] = ok ? oo : DD_OOB;
+          pr[tm][g8] = dd_bload16(rs_r, ok ? ((uint32_t)row * (uint32_t)p.ldres + (uint32_t)col) * 2u : DD_OOB);
+          if constexpr (PRE_ACC) pa[tm][g8] = dd_bload16(rs_ac, off_o[tm][g8]);
+        }
+      }
+    }
+  };
+  auto epi_finish = [&]() __attribute__((always_inline)) {   // operands are in registers: arithmetic + ES buffer stores
+#pragma unroll
+    for (auto& v : pb) dd_pin(v);
+#pragma unroll
+    for (auto& row : pr)
+#pragma unroll
+      for (auto& v : row) dd_pin(v);
+#pragma unroll
+    for (auto& row : pa)
+#pragma unroll
+      for (auto& v : row) dd_pin(v);
+    if constexpr (LNOUT) {
+      constexpr int NCOL = 320;
+      const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc(p.ln_out, 0, p.ln_out_bytes, 0x00020000);
+      float bias[8], ga[8], be[8];
+      dd_unpack8<T>(pb[0], bias);
+      dd_unpack8<T>(pb[1], ga);
+      dd_unpack8<T>(pb[2], be);
+      float v[TM][8], part[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        float r[8];
+        dd_unpack8<T>(pr[tm][0], r);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = (acc[e >> 2][tm][e & 3] + bias[e]) * p.alpha + r[e];
+          v[tm][e] = (float)(T)x;                             // the stored (rounded) value is what gets normalised
+          s += v[tm][e];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v[tm]), rs_st, off_o[tm][0], 0, 0);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        part[tm] = s;
+      }
+      // two-pass statistics over the rounded values, the 10 waves' partial sums combined through LDS in a fixed order
+      // (the arithmetic of store_tile_ln); raw barriers: __syncthreads() would drain the LDS-DMAs in flight
+      if (q4 == 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) s_ln[wave_n * BM + tm * 16 + c16] = part[tm];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      float mean[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += s_ln[w * BM + tm * 16 + c16];
+        mean[tm] = s * (1.0f / (float)NCOL);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[tm][e] - mean[tm]; ss += d * d; }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        part[tm] = ss;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (q4 == 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) s_ln[wave_n * BM + tm * 16 + c16] = part[tm];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        float ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ss += s_ln[w * BM + tm * 16 + c16];
+        const float rstd = rsqrtf(ss * (1.0f / (float)NCOL) + p.ln_eps);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[tm][e] - mean[tm]) * rstd * ga[e] + be[e];
+        __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(o), rs_ln, off_l[tm], 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the partials are read: the next tile may overwrite them
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (GEGLU) {
+      constexpr int TH = TN / 2;
+#pragma unroll
+      for (int g8 = 0; g8 < NG; ++g8) {
+        float bh[8], bg[8];
+        dd_unpack8<T>(pb[g8], bh);
+        dd_unpack8<T>(pb[NG + g8], bg);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[e] = dd_geglu_f(acc[g8 * 2 + (e >> 2)][tm][e & 3] + bh[e], acc[TH + g8 * 2 + (e >> 2)][tm][e & 3] + bg[e]);
+          __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
+          __builtin_amdgcn_sched_barrier(0);       // one group at a time: interleaved, the groups' temporaries spill
+        }
+      }
+    } else {
+      const bool silu = p.act == DD_EPI_SILU;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int g8 = 0; g8 < NG; ++g8) {
+          float v[8], b[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3];
+          dd_unpack8<T>(pb[g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (v[e] + b[e]) * p.alpha;
+          dd_unpack8<T>(pr[tm][g8], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+          if (silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = dd_silu_f(v[e]);
+          }
+          if constexpr (PRE_ACC) {
+            dd_unpack8<T>(pa[tm][g8], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= hmf[g8];
+          __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  };
+  // vmcnt immediates from scalar state: the `ahead` youngest stages, plus the epilogue operations issued after the
+  // certified stage; a combination without an instantiation waits for MORE (fewer operations left in flight): safe
+  auto wait_step = [&](const int ahead, const bool xl, const bool xs) __attribute__((always_inline)) {
+    if (ahead >= D - 2) {
+      if (!xl && !xs) wait_vmcnt_le<(D - 2) * LPS>();
+      else if (xl && xs) wait_vmcnt_le<(D - 2) * LPS + EL + ES>();
+      else if (xl) wait_vmcnt_le<(D - 2) * LPS + EL>();
+      else wait_vmcnt_le<(D - 2) * LPS + ES>();
+    } else if (D > 3 && ahead == D - 3) {
+      if (xl) wait_vmcnt_le<(D > 3 ? D - 3 : 0) * LPS + EL>(); else wait_vmcnt_le<(D > 3 ? D - 3 : 0) * LPS>();
+    } else if (D > 4 && ahead == D - 4) {
+      if (xl) wait_vmcnt_le<(D > 4 ? D - 4 : 0) * LPS + EL>(); else wait_vmcnt_le<(D > 4 ? D - 4 : 0) * LPS>();
+    } else if (ahead >= 1) {
+      if (xl) wait_vmcnt_le<LPS + EL>(); else wait_vmcnt_le<LPS>();
+    } else {
+      if (xl) wait_vmcnt_le<EL>(); else wait_vmcnt_le<0>();
+    }
+  };
+  auto wait_loads = [&](const int since) __attribute__((always_inline)) {   // `since` stages were issued behind the operand loads
+    if (since >= A + 1) wait_vmcnt_le<(A + 1) * LPS>();
+    else if (A >= 1 && since == A) wait_vmcnt_le<(A >= 1 ? A : 0) * LPS>();
+    else if (A >= 2 && since == A - 1) wait_vmcnt_le<(A >= 2 ? A - 1 : 0) * LPS>();
+    else if (since >= 1) wait_vmcnt_le<LPS>();
+    else wait_vmcnt_le<0>();
+  };
+
+  constexpr int OLD = 1 << 20;
+  using YES = std::true_type;
+  using NO = std::false_type;
+  int age_l = OLD, age_s = OLD;                    // stages issued since the operand loads / the stores went out
+  // One K-step = top (stage g + 1 certified, slot of stage g - 1 / g free) + body + bookkeeping.  Every loop below has ONE
+  // straight-line body: with the body variant chosen by a run-time branch inside one loop the accumulators are no longer
+  // updated in place (phis of MFMA results), the kernel needs two accumulator sets and spills fragments INSIDE the K loop
+  // — and a scratch reload waits vmcnt(0), i.e. for the whole ring (first form of this kernel: 118-315 spilled registers).
+  auto top = [&](const int ahead) __attribute__((always_inline)) {
+    wait_step(ahead, age_l <= ahead, age_s <= ahead);
+    if (TIGHT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto issued = [&]() __attribute__((always_inline)) { seam(); next_issue_tile(); ++age_l; ++age_s; };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- every tile but the last: each of its K-steps issues a stage (of this tile, then of the next) ------------------
+  for (int left = my_tiles; left > 1; --left) {
+    if constexpr (!LATE) {
+      for (int c = 0; c < nk - 1 - A; ++c) { top(D - 2); steady(YES{}, YES{}); issued(); }
+      top(D - 2);
+      epi_loads();                                 // A K-steps ahead of the tile's last one
+      age_l = 0;
+      __builtin_amdgcn_sched_barrier(0);
+      steady(YES{}, YES{});
+      issued();
+      for (int c = nk - A; c < nk - 1; ++c) { top(D - 2); steady(YES{}, YES{}); issued(); }
+    } else {
+      for (int c = 0; c < nk - 1; ++c) { top(D - 2); steady(YES{}, YES{}); issued(); }
+    }
+    top(D - 2);
+    steady(YES{}, NO{});                           // the tile's last K-step
+    issued();
+    if constexpr (LATE) { epi_loads(); wait_vmcnt<0>(); } else wait_loads(age_l);
+    epi_finish();
+    age_l = OLD;
+    age_s = 0;
+    zero_acc();
+    clin += G;
+    compute_tile(clin);
+    read_half(K0{});                               // stage 0 of the next tile: certified by the last step's barrier
+    read_half(K1{});
+    rslot = rslot + 1 == NSTAGE ? 0 : rslot + 1;
+  }
+  // ---- the last tile: dd_gemm3_kernel's flow — issue while stages remain, operand loads behind the last DMA, drain -----
+  int c = 0;
+  for (; c + D < nk; ++c) { top(D - 2); steady(YES{}, YES{}); issued(); }
+  if constexpr (!LATE) { epi_loads(); age_l = 0; __builtin_amdgcn_sched_barrier(0); }
+  for (; c + 1 < nk; ++c) { top(min(D - 2, nk - 2 - c)); steady(NO{}, YES{}); }
+  __builtin_amdgcn_s_setprio(1);
+  mfma_half(K0{});
+  mfma_half(K1{});
+  __builtin_amdgcn_s_setprio(0);
+  if constexpr (LATE) epi_loads();
+  wait_vmcnt<0>();
+  epi_finish();
+}
+
 // Kernel family 3: direct 3x3 convolution for SMALL images (14x25 and deeper: H*W <= 384).
 // The implicit-GEMM kernels stage the activation tile once per TAP (9 x per 64 input channels); at
 // the deep levels (336 / 1092 rows x 1280 channels x 29-59 MB of weights) that makes the kernel
@@ -1949,7 +2503,7 @@ inline int tile_bn(const TileCfg& t) { return t.wn * t.tn * 16; }
 
 constexpr int kNumCU = 256;
 
-struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; bool persist_ok; int band_rows, bands; };
+struct Plan { int tile_idx; int split; int tiles_m, tiles_n; int k_per_split; int g_per_tile, chunks_per_split; bool unsupported; bool persist_ok; int band_rows, bands; bool persist3_ok; };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -2092,6 +2646,18 @@ Plan make_plan(const dd_gemm_desc* d) {
     // LDS or per-tile LDS state, and a K loop at least as long as the ring.  DD_PERSIST=0 is the A/B switch.
     static const bool off = getenv("DD_PERSIST") && atoi(getenv("DD_PERSIST")) == 0;
     pl.persist_ok = !off && !d->conv && t.stages >= 2 && t.stages < 100 && split == 1 && !d->ln_colsum && !d->ln_out && nkt >= t.stages;
+    // persistent walk of the PIPELINED family (dd_gemm4_kernel, round 6): split == 1, K in whole steps and at least as long
+    // as the ring, an epilogue with a fixed number of memory operations (plain / head-major / GEGLU / the LayerNorm tile),
+    // buffer-descriptor addressing (31-bit extents).  DD_PERSIST3=0 is the A/B switch.
+    static const bool off3 = getenv("DD_PERSIST3") && atoi(getenv("DD_PERSIST3")) == 0;
+    const int ng = geglu ? t.tn / 4 : t.tn / 2;
+    const bool pre_acc = !geglu && t.id != 74 && t.tm * ng <= 4;
+    const int64_t ob = (((int64_t)d->rows - 1) * d->ldc + d->n) * 2, rb = (((int64_t)d->rows - 1) * d->ldres + d->n) * 2;
+    const int64_t lb = (((int64_t)d->rows - 1) * d->ld_ln_out + d->n) * 2;
+    pl.persist3_ok = !off3 && !d->conv && t.stages >= 100 && t.id != 76 && t.id != 77 && split == 1 && (d->k % BK) == 0 && nkt >= t.stages - 100 &&
+                     !d->out_f32 && !d->ln_stats_out && !d->rowvec && !d->ln_colsum && (!d->accumulate || pre_acc) &&
+                     ((t.id == 74) == (d->ln_out != nullptr)) && ob < ((int64_t)1 << 31) && (!d->res || rb < ((int64_t)1 << 31)) &&
+                     (!d->ln_out || lb < ((int64_t)1 << 31));
   }
   return pl;
 }
@@ -2152,6 +2718,35 @@ int launch_cfg3(const GemmParams& p, const Plan& pl, hipStream_t s) {
   return dd_check_launch();
 }
 
+// Workgroups of a pipelined tile that are resident per CU — decided from the tile alone (ring bytes and waves), not from an
+// occupancy query, so that dd_gemm_kernel_name reports the launcher's choice without a device: two 4-wave workgroups
+// where two rings fit the 160 KB of LDS (the 60 KB 96x64 ring; its kernels need <= 128 registers), else one.
+inline int gemm4_resident(const TileCfg& t) {
+  const int ring = (t.stages - 100) * (tile_bm(t) + tile_bn(t)) * BK * 2;
+  return (t.wm * t.wn == 4 && 2 * ring <= 160 * 1024) ? 2 : 1;
+}
+inline bool gemm4_takes(const Plan& pl) {          // the persistent form: more tiles than one residency generation
+  return pl.persist3_ok && pl.tiles_m * pl.tiles_n > kNumCU * gemm4_resident(kTiles[pl.tile_idx]);
+}
+
+// the persistent form when the tiles exceed one residency generation, else the one-tile-per-workgroup kernel
+template <typename T, int WM, int WN, int TM, int TN, int NSTAGE, bool GEGLU>
+int launch_cfg34(const GemmParams& p, const Plan& pl, hipStream_t s) {
+  if (pl.persist3_ok) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * sizeof(T);
+    auto kern = dd_gemm4_kernel<T, WM, WN, TM, TN, NSTAGE, GEGLU>;
+    const int g = kNumCU * gemm4_resident(kTiles[pl.tile_idx]);
+    if (gemm4_takes(pl)) {
+      static std::atomic<uint64_t> attr_done{0};
+      dd_ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem, attr_done);
+      hipLaunchKernelGGL(kern, dim3(g, 1, 1), dim3(64 * WM * WN), smem, s, p);
+      return dd_check_launch();
+    }
+  }
+  return launch_cfg3<T, WM, WN, TM, TN, NSTAGE, GEGLU>(p, pl, s);
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int NSW, int GRP = 1, bool BAND = false>
 int launch_conv3s(const GemmParams& p, const Plan& pl, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -2176,13 +2771,13 @@ int launch_tile(const GemmParams& p, const Plan& pl, hipStream_t s) {
     case 37: if constexpr (CONV && !GEGLU) return launch_conv3s<T, 2, 2, 6, 2, 6, 3>(p, pl, s); break;
 #endif
 #ifndef DD_DBG_ONLY_C3       // -DDD_DBG_ONLY_C3: the direct-conv family only (tools/conv3s_bound.sh)
-    case 72: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 3, false>(p, pl, s); break;
-    case 73: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
-    case 75: if constexpr (!CONV) return launch_cfg3<T, 4, 2, 3, 4, 3, GEGLU>(p, pl, s); break;
+    case 72: if constexpr (!GEGLU && !CONV) return launch_cfg34<T, 2, 2, 3, 2, 3, false>(p, pl, s); break;
+    case 73: if constexpr (!GEGLU && !CONV) return launch_cfg34<T, 2, 2, 3, 2, 5, false>(p, pl, s); break;
+    case 75: if constexpr (!CONV) return launch_cfg34<T, 4, 2, 3, 4, 3, GEGLU>(p, pl, s); break;
     case 76: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 4, false>(p, pl, s); break;
     case 77: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 2, 1, 2, 6, false>(p, pl, s); break;
-    case 78: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
-    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg3<T, 1, 10, 5, 2, 3, false>(p, pl, s); break;
+    case 78: if constexpr (!GEGLU && !CONV) return launch_cfg34<T, 2, 5, 5, 2, 3, false>(p, pl, s); break;
+    case 74: if constexpr (!GEGLU && !CONV) return launch_cfg34<T, 1, 10, 5, 2, 3, false>(p, pl, s); break;
 #endif
 #if !defined(DD_DBG_ONLY_P) && !defined(DD_DBG_ONLY_C3)
     case 11: return launch_cfg2<T, 2, 2, 4, 4, 2, CONV, GEGLU>(p, pl, s);
@@ -2321,8 +2916,8 @@ extern "C" const char* dd_gemm_kernel_name(const dd_gemm_desc* d) {
     return g_kname;
   }
   if (t.stages >= 100) {
-    snprintf(g_kname, sizeof(g_kname), "dd_gemm3_kernel<%s, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
-             d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.stages - 100,
+    snprintf(g_kname, sizeof(g_kname), "dd_gemm%d_kernel<%s, %d, %d, %d, %d, %d, %s> split=%d grid=%dx%d tile=%s",
+             gemm4_takes(pl) ? 4 : 3, d->dtype == DD_F16 ? "_Float16" : "__bf16", t.wm, t.wn, t.tm, t.tn, t.stages - 100,
              d->epilogue == DD_EPI_GEGLU ? "true" : "false", pl.split, pl.tiles_m, pl.tiles_n, t.name);
     return g_kname;
   }
@@ -2389,6 +2984,9 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
     p.res_bytes = fits && d->res ? (uint32_t)rb : 0u;
   }
   p.persist = 0;
+  p.inv_tiles_n = 1.0f / (float)(pl.tiles_n > 0 ? pl.tiles_n : 1);
+  p.inv_hm_d = d->out_headmajor_d > 0 ? 1.0f / (float)d->out_headmajor_d : 1.0f;
+  p.ln_out_bytes = d->ln_out ? (uint32_t)((((int64_t)d->rows - 1) * d->ld_ln_out + d->n) * 2) : 0u;
   p.partial = nullptr;
   p.dbg_stamps = nullptr;
 #ifdef DD_DBG_STAMP

@@ -156,7 +156,7 @@ void dd_gemm8_kernel(const Gemm8Params p) {
         }
         V4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)(h[r] * dd_gelu_erf_f(gt[r]));
+        for (int r = 0; r < 4; ++r) o[r] = (T)dd_geglu_f(h[r], gt[r]);
         *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out) + (int64_t)row * p.ldc + ch) = o;
       }
     } else {

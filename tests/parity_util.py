@@ -18,7 +18,7 @@ Besides that, every row logs
   * e_floor_r1: the ROUND-1 floor (module-boundary rounding only, `storage_emulation(legacy=True)`) where the
     test computes it, and then ALSO requires e(HIP) <= 1.5 x e_floor_r1 — the round-1 acceptance rule, so
     the redefinition of the yardstick in round 2 cannot hide a regression.
-CSV: DD_PARITY_CSV (default gpurun_out/r05_parity.csv; the copy judged is profiles/r05_parity.csv).
+CSV: DD_PARITY_CSV (default gpurun_out/r06_parity.csv; the copy judged is profiles/r06_parity.csv).
 """
 import os
 
@@ -39,7 +39,7 @@ def rel_l2(y, ref):
 
 
 def _csv_path():
-    return os.environ.get("DD_PARITY_CSV", os.path.join(_ROOT, "gpurun_out", "r05_parity.csv"))
+    return os.environ.get("DD_PARITY_CSV", os.path.join(_ROOT, "gpurun_out", "r06_parity.csv"))
 
 
 def log_row(name, dtype, e_hip, e_floor, bnd, e_vs_emul=float("nan"), e_floor_r1=float("nan")):

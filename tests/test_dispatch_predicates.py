@@ -134,7 +134,12 @@ def test_gemm_plans_exist_for_every_level_of_every_resolution():
                 for tile in (72, 73, 74, 75, 76, 77, 78):
                     d.tile = tile
                     nm = lib.dd_gemm_kernel_name(ctypes.byref(d)).decode()
-                    assert nm.startswith("dd_gemm3_kernel"), (tile, nm)
+                    # one tile per workgroup, or (round 6) the persistent walk when the grid exceeds one generation
+                    # of resident workgroups and the K loop is at least as long as the ring
+                    tiles = [int(v) for v in nm.split("grid=")[1].split(" ")[0].split("x")]
+                    depth = {72: 3, 73: 5, 75: 3, 78: 3}.get(tile)
+                    many = depth is not None and tiles[0] * tiles[1] > 256 * (2 if tile == 72 else 1) and k // 64 >= depth
+                    assert nm.startswith("dd_gemm4_kernel" if many else "dd_gemm3_kernel"), (tile, nm)
                 d.tile = 0
 
 
