@@ -1419,7 +1419,9 @@ void dd_gemm3_kernel(const GemmParams p) {
 // absent operands and out-of-range rows are descriptor range checks, never predication), and the wait in front of a
 // K-step allows, besides the younger stages, exactly those epilogue operations that were issued AFTER the stage it
 // certifies (two scalar ages, counted in issued stages).  Same arithmetic in the same order per accumulator as
-// dd_gemm3_kernel / dd_gemm2_kernel -> bit-identical results.
+// dd_gemm3_kernel / dd_gemm2_kernel -> bit-identical results, but for the last rounding of two epilogues, where the compiler
+// contracts multiply (+ add) and the conversion to T differently than in store8 / store_tile_ln (one ulp on < 0.01 % of the
+// elements: the scaled head-major planes, LayerNorm(out); tests/test_gemm4_gpu.py).
 // Dense, no split-K, K >= D steps (host-checked); epilogues: plain (bias, alpha, residual, SiLU, accumulate, head-major
 // planes), GEGLU, and the LayerNorm-emitting 80 x 320 tile.
 // =============================================================================================
@@ -2557,9 +2559,12 @@ Plan make_plan(const dd_gemm_desc* d) {
   if (ti >= 0 && kTiles[ti].stages >= 100 && (d->conv || (d->ln_out && kTiles[ti].id != 74))) { pl.unsupported = true; return pl; }   // dense only
   if (d->ln_out) {                                   // LayerNorm-emitting epilogue: the 80x320 tile, one column tile
     if (d->tile > 0 && d->tile != 40 && d->tile != 74) { pl.unsupported = true; return pl; }
-    // auto: the pipelined form (round 5: +0.4 % on the one-scene step) while its row tiles are one residency generation
-    // (153 KB of LDS: one workgroup per CU); beyond that the dd_gemm2 form's persistent walk wins (4 scenes: -1.6 % otherwise)
-    const int want = d->tile > 0 ? d->tile : (ceil_div(d->rows, 80) <= kNumCU ? 74 : 40);
+    // auto: the pipelined form — one tile per workgroup while its row tiles are one residency generation (153 KB of LDS: one
+    // workgroup per CU), the persistent walk of dd_gemm4_kernel beyond (round 6: 67200 x 320 x 320 46.5 us against 56.4 for
+    // the dd_gemm2 form's walk, x 1280 112.7 against 143.7: profiles/r06_gemm3_bound.txt); with DD_PERSIST3=0 the round-5
+    // rule (beyond one generation the dd_gemm2 form, tile 40)
+    static const bool off3 = getenv("DD_PERSIST3") && atoi(getenv("DD_PERSIST3")) == 0;
+    const int want = d->tile > 0 ? d->tile : ((!off3 || ceil_div(d->rows, 80) <= kNumCU) ? 74 : 40);
     for (int i = 0; i < kNumTiles; ++i) if (kTiles[i].id == want) ti = i;
     if (d->n != 320 || !dma_ok(d)) { pl.unsupported = true; return pl; }
   }

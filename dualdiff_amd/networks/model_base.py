@@ -83,7 +83,7 @@ class ForwardGraphs:
         switches.  `use_aug_text` is an argument of every call (and written back by prepare_tokens): not a flag."""
         from . import box_adapter, unet_addon_rawbox
         return tuple(sorted((k, v) for k, v in vars(module).items()
-                            if not k.startswith("_") and k not in ("training", "use_aug_text")
+                            if not k.startswith("_") and k not in ("training", "use_aug_text", "graph_forward")
                             and isinstance(v, (bool, int, float, str, type(None))))) \
             + tuple(sorted((k, v is None) for k, v in module._modules.items())) \
             + (("SPLIT_SIZE", box_adapter.SPLIT_SIZE), ("XATTN_FUSED", _layers.XATTN_FUSED),

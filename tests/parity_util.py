@@ -72,3 +72,35 @@ def report(name, y, ref, dtype, record, emul=None, emul_legacy=None):
     if emul_legacy is not None:
         ratio = max(ratio, e / max(1e-3, LEGACY_SLACK * fl1))
     return ratio
+
+
+# ---- cached oracle outputs -----------------------------------------------------------------------------------------
+# The slowest part of the GPU suite is the CPU oracle itself (2 x 12-instance dual-branch steps in three numerics: 110 s;
+# the 48-instance video UNet: 120 s): 850-950 s of a 1200 s step limit on the driver's box.  The
+# oracle's outputs for the FIXED seeded cases of those tests are therefore kept as data under tests/golden/oracle_cache/
+# (like tests/golden/trajectory_ddim50.npz: the build's own oracle, labelled so — inputs and weights are regenerated from
+# their seeds, only the outputs are stored).  Minting: `bash tests/golden/mint_oracle_cache.sh` = the same tests with
+# DD_MINT_ORACLE=<dir>, which recomputes every cached case with the live oracle, writes it AND compares it with what is
+# stored.  A missing file is computed on the spot: the comparison with the oracle happens either way.
+ORACLE_CACHE = os.path.join(_ROOT, "tests", "golden", "oracle_cache")
+
+
+def oracle_cache(name, compute):
+    """compute() -> {key: fp32 tensor}: loaded from tests/golden/oracle_cache/<name>.npz when it exists."""
+    import numpy as np
+    path = os.path.join(ORACLE_CACHE, name + ".npz")
+    mint = os.environ.get("DD_MINT_ORACLE")
+    have = None
+    if os.path.exists(path):
+        with np.load(path) as z:
+            have = {k: torch.from_numpy(z[k].astype("float32")) for k in z.files}
+        if not mint:
+            return have
+    out = {k: v.detach().float().cpu().contiguous() for k, v in compute().items()}
+    if mint:
+        os.makedirs(mint, exist_ok=True)
+        np.savez_compressed(os.path.join(mint, name + ".npz"), **{k: v.numpy() for k, v in out.items()})
+        if have is not None:                      # the stored outputs are the live oracle's (other host CPU: ~1e-6)
+            for k, v in out.items():
+                assert rel_l2(have[k], v) < 1e-4, (name, k)
+    return out

@@ -58,14 +58,23 @@ def unet_case(gpu):
         return ora(sample, torch.tensor(481), encoder_hidden_states=ctx, down_block_additional_residuals=down,
                    mid_block_additional_residual=mid).sample
 
-    with torch.no_grad():
-        ref = run()
-        emul = {}
-        for dt in DTYPES:
-            with storage_emulation(ora, dt):
-                emul[dt] = run()
-            with storage_emulation(ora, dt, legacy=True):          # the round-1 floor, logged beside the current one
-                emul[("r1", dt)] = run()
+    def oracle():
+        out = {}
+        with torch.no_grad():
+            out["ref"] = run()
+            for dt in DTYPES:
+                tag = str(dt).split(".")[-1]
+                with storage_emulation(ora, dt):
+                    out["emul_" + tag] = run()
+                with storage_emulation(ora, dt, legacy=True):      # the round-1 floor, logged beside the current one
+                    out["r1_" + tag] = run()
+        return out
+    from tests.parity_util import oracle_cache
+    o = oracle_cache("unet_multiview_forward", oracle)
+    ref, emul = o["ref"], {}
+    for dt in DTYPES:
+        tag = str(dt).split(".")[-1]
+        emul[dt], emul[("r1", dt)] = o["emul_" + tag], o["r1_" + tag]
     return sd, sample, ctx, down, mid, ref, emul
 
 

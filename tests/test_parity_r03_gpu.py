@@ -28,7 +28,7 @@ from oracle import video_restated as V
 from oracle.init_utils import seeded_state_dict, seeded_tensor
 from oracle.numerics import storage_emulation
 from tests.golden import cases as C
-from tests.parity_util import rel_l2, report
+from tests.parity_util import oracle_cache, rel_l2, report
 
 pytestmark = pytest.mark.gpu
 
@@ -80,8 +80,15 @@ def bench_context_case(gpu):
                 outs.append(x[0].clone())
         return outs
 
-    ref = run(None)
-    floors = {dt: run(dt) for dt in (torch.float16, torch.bfloat16)}
+    def oracle():
+        out = {}
+        for tag, dt in (("ref", None), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+            for i, x in enumerate(run(dt)):
+                out["%s_%d" % (tag, i)] = x
+        return out
+    o = oracle_cache("bench_context_two_steps", oracle)
+    ref = [o["ref_0"], o["ref_1"]]
+    floors = {torch.float16: [o["f16_0"], o["f16_1"]], torch.bfloat16: [o["bf16_0"], o["bf16_1"]]}
     return usd, csd, inp, ref, floors
 
 
@@ -135,10 +142,14 @@ def test_video_unet_forward_T8(gpu, dtype):
     def run():
         return ora(sample, torch.tensor(481), encoder_hidden_states=ctx, down_block_additional_residuals=down,
                    mid_block_additional_residual=mid).sample
-    with torch.no_grad():
-        ref = run()
-        with storage_emulation(ora, dtype):
-            emul = run()
+    def oracle():
+        with torch.no_grad():
+            ref = run()
+            with storage_emulation(ora, dtype):
+                emul = run()
+        return {"ref": ref, "emul": emul}
+    o = oracle_cache("video_unet_T8_f16", oracle)
+    ref, emul = o["ref"], o["emul"]
     net = UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames)
     net.load_state_dict(sd, strict=True)
     net = net.to("cuda", dtype).eval()

@@ -92,10 +92,15 @@ def test_video_unet_forward(gpu, dtype):
     def run():
         return ora(sample, torch.tensor(481), encoder_hidden_states=ctx, down_block_additional_residuals=down,
                    mid_block_additional_residual=mid).sample
-    with torch.no_grad():
-        ref = run()
-        with storage_emulation(ora, dtype):
-            emul = run()
+    def oracle():
+        with torch.no_grad():
+            ref = run()
+            with storage_emulation(ora, dtype):
+                emul = run()
+        return {"ref": ref, "emul": emul}
+    from tests.parity_util import oracle_cache
+    o = oracle_cache("video_unet_T2_%s" % str(dtype).split(".")[-1], oracle)
+    ref, emul = o["ref"], o["emul"]
     net = UNet2DConditionModelMultiviewVideo(cross_attention_dim=768, neighboring_view_pair=PAIR, n_frames=frames)
     net.load_state_dict(sd, strict=True)
     net = net.to("cuda", dtype).eval()
