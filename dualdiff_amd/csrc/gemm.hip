@@ -1440,6 +1440,14 @@ __device__ __forceinline__ u32x4 dd_bload16(u32x4 rsrc, uint32_t voff, uint32_t 
 }
 __device__ __forceinline__ void dd_pin(u32x4& v) { asm volatile("" : "+v"(v)); }   // uses of v stay behind this point
 
+// Diagnostic builds (tools/gemm4_bound.sh; never the product): -DDD_DBG_NOSTORE drops the epilogue's stores of
+// dd_gemm4_kernel, -DDD_DBG_NOLDS its fragment reads in the K loop (results are garbage: timing only).
+#ifdef DD_DBG_NOSTORE
+#define DD_G4_STORE(...) ((void)0)
+#else
+#define DD_G4_STORE(...) __builtin_amdgcn_raw_buffer_store_b128(__VA_ARGS__)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_le() {          // vmcnt(min(N, 63)): waiting for MORE than asked is always safe
   wait_vmcnt<(N > 63 ? 63 : N)>();
@@ -1642,6 +1650,9 @@ void dd_gemm4_kernel(const GemmParams p) {
       else bdma16(rs_x, xe[u - WI], so_x, xs + ((u - WI) * NW + wave) * 8 * BK);
     };
     auto rd = [&](const int ks, const int u) __attribute__((always_inline)) {
+#ifdef DD_DBG_NOLDS
+      return;
+#endif
       if (u < TN) wf[ks][u] = dd_as_v8<T>(dd_ld16((ks ? wp1 : wp0) + u * 16 * BK));
       else xf[ks][u - TN] = dd_as_v8<T>(dd_ld16((ks ? xp1 : xp0) + (u - TN) * 16 * BK));
     };
@@ -1775,7 +1786,7 @@ void dd_gemm4_kernel(const GemmParams p) {
           v[tm][e] = (float)(T)x;                             // the stored (rounded) value is what gets normalised
           s += v[tm][e];
         }
-        __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v[tm]), rs_st, off_o[tm][0], 0, 0);
+        DD_G4_STORE(dd_pack8<T>(v[tm]), rs_st, off_o[tm][0], 0, 0);
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         part[tm] = s;
@@ -1819,7 +1830,7 @@ void dd_gemm4_kernel(const GemmParams p) {
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[tm][e] - mean[tm]) * rstd * ga[e] + be[e];
-        __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(o), rs_ln, off_l[tm], 0, 0);
+        DD_G4_STORE(dd_pack8<T>(o), rs_ln, off_l[tm], 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the partials are read: the next tile may overwrite them
       __builtin_amdgcn_s_barrier();
@@ -1836,12 +1847,29 @@ void dd_gemm4_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             v[e] = dd_geglu_f(acc[g8 * 2 + (e >> 2)][tm][e & 3] + bh[e], acc[TH + g8 * 2 + (e >> 2)][tm][e & 3] + bg[e]);
-          __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
+          DD_G4_STORE(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
           __builtin_amdgcn_sched_barrier(0);       // one group at a time: interleaved, the groups' temporaries spill
         }
       }
     } else {
       const bool silu = p.act == DD_EPI_SILU;
+      // a projection without bias, residual, accumulation or activation (the fused Q|K|V GEMM: a sixth of the dense launches)
+      // skips the operand arithmetic — 12 of the ~50 vector instructions per 8 outputs remain (uniform branch; the operand
+      // loads were issued all the same: their count is what the waits rely on)
+      const bool bare = !p.bias && !p.res && !p.accumulate && !silu && p.alpha == 1.0f;
+      if (bare) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int g8 = 0; g8 < NG; ++g8) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[g8 * 2 + (e >> 2)][tm][e & 3] * hmf[g8];
+            DD_G4_STORE(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        return;
+      }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1866,7 +1894,7 @@ void dd_gemm4_kernel(const GemmParams p) {
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= hmf[g8];
-          __builtin_amdgcn_raw_buffer_store_b128(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
+          DD_G4_STORE(dd_pack8<T>(v), rs_st, off_o[tm][g8], 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -5,7 +5,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$PWD; L=$R/dualdiff_amd/lib
 [ -f $L/obj/norm.o ] || python3 -c "from dualdiff_amd import _build; _build.build_native(force=True)" 2>/dev/null
-VARS="NODMA NOMFMA NODMA+NOMFMA"
+VARS="${G4_VARIANTS:-NODMA NOMFMA NODMA+NOMFMA NODMA+NOMFMA+NOSTORE NODMA+NOMFMA+NOSTORE+NOLDS}"
 for V in $VARS; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-unused-value -DNDEBUG -mllvm -amdgpu-mfma-vgpr-form=1 \
     $(for f in $(echo $V | tr + ' '); do echo -n "-DDD_DBG_$f "; done) -c $R/dualdiff_amd/csrc/gemm.hip -o /tmp/gemm_$V.o &
