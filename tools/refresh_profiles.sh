@@ -4,7 +4,7 @@
 # Every run uses the TRACKED tile table (dualdiff_amd/tuned/gfx950.json): same kernels in every process.
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
