@@ -1435,7 +1435,11 @@ __device__ __forceinline__ u32x4 dd_rsrc_words(const void* base, uint32_t bytes)
 }
 __device__ __forceinline__ u32x4 dd_bload16(u32x4 rsrc, uint32_t voff, uint32_t soff = 0) {
   u32x4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  // s_nop 4: a descriptor word the compiler has just produced with a VALU instruction (v_readlane of a spilled SGPR,
+  // v_readfirstlane) needs 5 wait states before a vector-memory instruction may read it, and the hazard recogniser does not
+  // look inside inline asm — without it a build whose register allocation spills scalars read garbage descriptors here
+  // (round 6: NaNs in the biased epilogues of the 10-wave tiles, profiles/r06_experiments.txt section 8)
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   return v;
 }
 __device__ __forceinline__ void dd_pin(u32x4& v) { asm volatile("" : "+v"(v)); }   // uses of v stay behind this point
@@ -1483,6 +1487,11 @@ void dd_gemm4_kernel(const GemmParams p) {
   // out IN the epilogue and it waits for everything in flight — the stages of the next tile keep landing meanwhile.
   constexpr bool LATE = NW > 8;
   constexpr int A = LATE ? 0 : D - 1;
+#ifdef DD_DBG_NOSECTOR
+  constexpr bool SECTOR = false;
+#else
+  constexpr bool SECTOR = !GEGLU && TN == 4;                   // plain 16-column lanes: sector-contiguous stores (see make_wv)
+#endif
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
   static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
   static_assert(NSTAGE >= 3 && NSTAGE <= 8 && D >= 3, "NSTAGE");
@@ -1525,6 +1534,12 @@ void dd_gemm4_kernel(const GemmParams p) {
         const int t = tn % TH;
         const int col = bn0 + wvi * (TH * 16) + (r >> 2) * (4 * TH) + t * 4 + (r & 3);
         n_glob = (col < p.n) ? col + (tn >= TH ? p.n : 0) : -1;
+      } else if (SECTOR) {
+        // a lane's 16 columns as two 8-column groups 32 columns apart: the four lanes of a row then write 64 CONTIGUOUS
+        // bytes per store instruction (whole 32-byte sectors) instead of four 16-byte pieces interleaved with the other
+        // group's (every sector written half by one instruction, half by the next)
+        const int col = bn0 + wvi * (TN * 16) + (tn >> 1) * 32 + (r >> 2) * 8 + (tn & 1) * 4 + (r & 3);
+        n_glob = (col < p.n) ? col : -1;
       } else {
         const int col = bn0 + wvi * (TN * 16) + (r >> 2) * (4 * TN) + tn * 4 + (r & 3);
         n_glob = (col < p.n) ? col : -1;
@@ -1737,10 +1752,10 @@ void dd_gemm4_kernel(const GemmParams p) {
         }
       }
     } else {
-      const int ecol0 = block_n0 + wave_n * (TN * 16) + q4 * (4 * TN);
+      const int ecol0 = block_n0 + wave_n * (TN * 16) + (SECTOR ? q4 * 8 : q4 * (4 * TN));
 #pragma unroll
       for (int g8 = 0; g8 < NG; ++g8) {
-        const int col = ecol0 + g8 * 8;
+        const int col = ecol0 + g8 * (SECTOR ? 32 : 8);
         pb[g8] = dd_bload16(rs_b, col < p.n ? (uint32_t)col * 2u : DD_OOB);
         int plane = 0;
         hmf[g8] = 1.0f;

@@ -437,3 +437,18 @@ def test_pmc_summary_counts_only_the_timed_steps(tmp_path):
     # the bench line's lookup reads the same structure
     import bench
     assert abs(bench._pmc_traffic("dd_gemm2_kernel_tiny", k) - want) < 1.0
+
+
+def test_inline_asm_vector_memory_loads_carry_their_own_wait_states():
+    """Round 6: a buffer descriptor restored from a spilled scalar (v_readlane) or made uniform (v_readfirstlane) right in
+    front of an inline-asm buffer load is read 5 wait states too early — the compiler's hazard recogniser does not look
+    inside asm.  Every inline-asm vector-memory load of the kernels therefore starts with its own `s_nop 4`."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dualdiff_amd", "csrc")
+    seen = 0
+    for path in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        for m in re.finditer(r'asm volatile\("([^"]*(?:buffer_load|global_load|buffer_store|global_store)[^"]*)"', open(path).read()):
+            seen += 1
+            assert m.group(1).startswith("s_nop 4"), (path, m.group(1))
+    assert seen >= 1
