@@ -96,6 +96,9 @@ __device__ __forceinline__ float dd_gelu_erf_f(float x) {
 // erf, no sign transfer and no 1 + erf.  (Round 6: the epilogue of the 16800 x 2560 x 320 GEGLU projection evaluates
 // 21.5 M gates — 11 us of vector issue at 84 cycles per wave-instruction group.)
 __device__ __forceinline__ float dd_geglu_f(float h, float g) {
+#ifdef DD_DBG_GEGLU_CHEAP                 // diagnostic build (never the product): what the gate's arithmetic costs a launch
+  return h * g;
+#endif
   const float ax = fabsf(g);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
   float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
