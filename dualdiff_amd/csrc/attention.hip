@@ -16,13 +16,7 @@
 //  * kv_batch_map + accumulate implement the neighbour-view attention (attn4) as two calls
 //    that read the neighbours' K/V in place and sum the normalised outputs.
 #include "dd_common.h"
-
-// DD_DBG_NOEXP (diagnostic build only, tools/build_dbg_libs.sh): the exponentials of the softmax become moves
-#ifdef DD_DBG_NOEXP
-#define DD_EXP2(x) (x)
-#else
-#define DD_EXP2(x) __builtin_amdgcn_exp2f(x)
-#endif
+#include "dd_debug.h"      // DD_EXP2, dd_dbg::NOSTAGE: hooks of the diagnostic builds (the product's are v_exp_f32 / false)
 // max of 8 scores as three v_max3_f32 + one v_max_f32 (a balanced fmaxf tree compiles to seven v_max_f32: the d = 40 loop is
 // VALU-issue-bound and this is 9 instructions of ~70 per 32-key chunk)
 __device__ __forceinline__ float dd_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -199,18 +193,14 @@ void dd_attn5_kernel(const AttnParams p) {
   u32x4 kreg[PER], vreg[PER];
   auto load_kv = [&](int tile0) {
     const uint32_t ko = (uint32_t)tile0 * k_row_bytes, vo = (uint32_t)tile0 * v_row_bytes;
-#ifdef DD_DBG_NOSTAGE      // diagnostic build: no K / V staging at all (the tiles hold garbage)
-    (void)ko; (void)vo; return;
-#endif
+    if constexpr (dd_dbg::NOSTAGE) return;
 #pragma unroll
     for (int i = 0; i < PER; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_k, gk[i] + ko, 0, 0);
 #pragma unroll
     for (int i = 0; i < PER; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, gv[i] + vo, 0, 0);
   };
   auto store_kv = [&](T* tile) {
-#ifdef DD_DBG_NOSTAGE
-    (void)tile; return;
-#endif
+    if constexpr (dd_dbg::NOSTAGE) return;
 #pragma unroll
     for (int i = 0; i < PER; ++i)
       if (i < PER - 1 || last_slot) {

@@ -18,6 +18,7 @@
 //    the same XCD (private L2).
 //  * split-K for the deep, weight-bound levels (336..1092 rows x K up to 23040).
 #include "dd_common.h"
+#include "dd_debug.h"
 #include <type_traits>
 
 namespace {
@@ -638,23 +639,15 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // offset.  An offset outside the descriptor's range reads zeros (hardware range check), which is how
 // padding taps and tile tails are produced — no 64-bit pointer arithmetic, no select against a zero page.
 __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, void* lds_wave_base) {
-#ifndef DD_DBG_NODMA
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
-                                           (int)voff, (int)soff, 0, 0);
-#endif
+  if constexpr (!dd_dbg::NODMA)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                             (int)voff, (int)soff, 0, 0);
 }
 // every buffer is < 2^31 bytes (checked on the host), so this lane offset is out of range whatever
 // scalar offset is added to it
 constexpr uint32_t DD_OOB = 0x80000000u;
 
-// DD_DBG_STAMP (diagnostic build only, tools/build_dbg_libs.sh): wave 0 of every workgroup of the direct conv records
-// s_memtime at phase boundaries plus s_memrealtime at both ends into the LAST MiB of the workspace (ops.py over-allocates
-// it when DD_DBG_STAMP_WS=1); nothing reads them on the device.
-#ifdef DD_DBG_STAMP
-#define DD_STAMP(i) do { if (threadIdx.x == 0) dbg_t[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DD_STAMP(i) do {} while (0)
-#endif
+// DD_STAMP*, C3_SEG*, dd_dbg::*: hooks of the diagnostic builds, all empty / false in the product (dd_debug.h).
 
 // Occupancy target (round 3): the DENSE four-wave instantiations had grown to 240-272 registers (LayerNorm fold, row
 // statistics, head-major planes, persistent walk ... all live in one body), i.e. ONE wave per SIMD and one workgroup per CU
@@ -683,10 +676,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   static_assert(NSTAGE >= 2 && NSTAGE <= 8, "NSTAGE");
   static_assert((NSTAGE - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
 
-#ifdef DD_DBG_STAMP
-  uint64_t dbg_t[6];
-  const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  DD_STAMP_DECL();
   DD_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);
@@ -829,11 +819,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   auto issue_next = [&](int slot) __attribute__((always_inline)) {
     T* xs = ring + slot * STAGE;
     T* ws = xs + BM * BK;
-#ifdef DD_DBG_SAMEK      // diagnostic: every K-step re-stages the SAME bytes (L1-resident after the first step)
-    const uint32_t ksoff = 0u;
-#else
-    const uint32_t ksoff = (uint32_t)ik0 * 2u;
-#endif
+    const uint32_t ksoff = dd_dbg::SAMEK ? 0u : (uint32_t)ik0 * 2u;
 #pragma unroll
     for (int j = 0; j < WI; ++j) bdma16(rs_w, wv[j], ksoff, ws + (j * NW + wave) * 8 * BK);
     if (CONV) {
@@ -994,9 +980,7 @@ void dd_gemm2_kernel(const GemmParams p) {
   have_next = persist && lin + (int)gridDim.x < ntiles;
   for (int kt = 0; kt < nk; kt += 2) {
     kstep(kt);
-#ifdef DD_DBG_STAMP
-    if (kt == 0) DD_STAMP(3);                  // after the first K-step
-#endif
+    DD_STAMP_IF(kt == 0, 3);                   // after the first K-step
     if (kt + 1 < nk) kstep(kt + 1);
   }
   DD_STAMP(4);
@@ -1020,15 +1004,7 @@ void dd_gemm2_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-#ifdef DD_DBG_STAMP
-  DD_STAMP(5);
-  if (threadIdx.x == 0 && p.dbg_stamps) {
-    uint64_t* o = p.dbg_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
-    for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
-    o[6] = dbg_r0;
-    o[7] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  DD_STAMP_FLUSH(p);
 }
 
 // =============================================================================================
@@ -1092,10 +1068,7 @@ void dd_gemm3_kernel(const GemmParams p) {
   static_assert(NSTAGE >= 3 && NSTAGE <= 8 && D >= 2, "NSTAGE");
   static_assert((D - 1) * LPS <= 63 && (D - 2) * LPS + EPI <= 63, "vmcnt is a 6-bit counter");
 
-#ifdef DD_DBG_STAMP
-  uint64_t dbg_t[6];
-  const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  DD_STAMP_DECL();
   DD_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);
@@ -1302,9 +1275,7 @@ void dd_gemm3_kernel(const GemmParams p) {
     __builtin_amdgcn_s_barrier();
     steady(std::true_type{});
     seam();
-#ifdef DD_DBG_STAMP
-    if (c == 0) DD_STAMP(3);
-#endif
+    DD_STAMP_IF(c == 0, 3);
   }
 
   // ---- epilogue operands: issued behind the last DMA -------------------------------------------------------------
@@ -1394,15 +1365,7 @@ void dd_gemm3_kernel(const GemmParams p) {
     }
   }
   if (!done) store_tile<T, TM, TN, GEGLU>(p, acc, block_m0, block_n0, wave_m, wave_n, lane, p.rows);
-#ifdef DD_DBG_STAMP
-  DD_STAMP(5);
-  if (threadIdx.x == 0 && p.dbg_stamps) {
-    uint64_t* o = p.dbg_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
-    for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
-    o[6] = dbg_r0;
-    o[7] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  DD_STAMP_FLUSH(p);
 }
 
 // =============================================================================================
@@ -1444,19 +1407,7 @@ __device__ __forceinline__ u32x4 dd_bload16(u32x4 rsrc, uint32_t voff, uint32_t 
 }
 __device__ __forceinline__ void dd_pin(u32x4& v) { asm volatile("" : "+v"(v)); }   // uses of v stay behind this point
 
-// Diagnostic builds (tools/gemm4_bound.sh; never the product): -DDD_DBG_NOSTORE drops the epilogue's stores of
-// dd_gemm4_kernel, -DDD_DBG_NOLDS its fragment reads in the K loop (results are garbage: timing only).
-#ifndef DD_DBG_STORE_AUX                  // cache-policy bits of the epilogue stores: 0 default, 2 = nt, 16 = sc1 (diagnostic)
-#define DD_DBG_STORE_AUX 0
-#endif
-#ifdef DD_DBG_NOSTORE
-#define DD_G4_STORE(...) ((void)0)
-#elif defined(DD_DBG_ONESTORE)            // only the first store of a lane's tile goes out (does the stall scale with the bytes?)
-#define DD_G4_STORE(data, rsrc, voff, soff, aux) do { if (g4_first) __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voff, soff, 0); g4_first = false; } while (0)
-#else
-#define DD_G4_STORE(data, rsrc, voff, soff, aux) __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voff, soff, DD_DBG_STORE_AUX)
-#endif
-
+// DD_G4_STORE: the epilogue's 16-byte buffer store (dd_debug.h; the diagnostic builds of tools/gemm4_bound.sh drop it).
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_le() {          // vmcnt(min(N, 63)): waiting for MORE than asked is always safe
   wait_vmcnt<(N > 63 ? 63 : N)>();
@@ -1487,11 +1438,7 @@ void dd_gemm4_kernel(const GemmParams p) {
   // out IN the epilogue and it waits for everything in flight — the stages of the next tile keep landing meanwhile.
   constexpr bool LATE = NW > 8;
   constexpr int A = LATE ? 0 : D - 1;
-#ifdef DD_DBG_NOSECTOR
-  constexpr bool SECTOR = false;
-#else
-  constexpr bool SECTOR = !GEGLU && TN == 4;                   // plain 16-column lanes: sector-contiguous stores (see make_wv)
-#endif
+  constexpr bool SECTOR = !dd_dbg::NOSECTOR && !GEGLU && TN == 4;   // plain 16-column lanes: sector-contiguous stores (see make_wv)
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "tile/waves mismatch");
   static_assert(TN % 2 == 0 && (!GEGLU || TN % 4 == 0), "TN");
   static_assert(NSTAGE >= 3 && NSTAGE <= 8 && D >= 3, "NSTAGE");
@@ -1670,9 +1617,7 @@ void dd_gemm4_kernel(const GemmParams p) {
       else bdma16(rs_x, xe[u - WI], so_x, xs + ((u - WI) * NW + wave) * 8 * BK);
     };
     auto rd = [&](const int ks, const int u) __attribute__((always_inline)) {
-#ifdef DD_DBG_NOLDS
-      return;
-#endif
+      if constexpr (dd_dbg::NOLDS) return;
       if (u < TN) wf[ks][u] = dd_as_v8<T>(dd_ld16((ks ? wp1 : wp0) + u * 16 * BK));
       else xf[ks][u - TN] = dd_as_v8<T>(dd_ld16((ks ? xp1 : xp0) + (u - TN) * 16 * BK));
     };
@@ -1777,9 +1722,7 @@ void dd_gemm4_kernel(const GemmParams p) {
     }
   };
   auto epi_finish = [&]() __attribute__((always_inline)) {   // operands are in registers: arithmetic + ES buffer stores
-#ifdef DD_DBG_ONESTORE
-    bool g4_first = true;
-#endif
+    DD_G4_STORE_STATE();
 #pragma unroll
     for (auto& v : pb) dd_pin(v);
 #pragma unroll
@@ -2024,23 +1967,7 @@ void dd_gemm4_kernel(const GemmParams p) {
 // pixels (whole image rows) of one instance; its slab holds those pixels plus a halo of W + 1 pixels on either side, so
 // the activation is still staged once per 64-channel chunk (the implicit-GEMM kernels stage it once per tap).  LDS rows
 // 0..15 are the zero rows, slab pixel s sits in row 16 + s; halo pixels outside the image are out-of-range DMAs = zeros.
-// Diagnostic builds (tools/conv3s_bound.sh; never the product): which side of the (chunk, tap) step sets its length.
-//   -DDD_DBG_C3_NOMFMA   the matrix instructions are dropped (operands stay live)
-//   -DDD_DBG_C3_NOGATHER the activation fragments are gathered once, at step 0
-//   -DDD_DBG_C3_NOWREAD  the weight fragments are read once, at step 0
-//   -DDD_DBG_C3_NOBAR    no workgroup barrier in the loop
-//   -DDD_DBG_C3_NOWAIT   no s_waitcnt vmcnt in the loop (operands may be stale: timing only)
-//   -DDD_DBG_C3_NODMA    no DMA issued in the loop (only the prologue's)
-#ifdef DD_DBG_C3_NOMFMA
-#define C3_MFMA(w, x, a) ([&]() { asm volatile("" :: "v"(w), "v"(x)); return a; }())
-#else
-#define C3_MFMA(w, x, a) dd_mfma16(w, x, a)
-#endif
-#ifdef DD_DBG_C3_NOBAR
-#define C3_BARRIER() ((void)0)
-#else
-#define C3_BARRIER() __builtin_amdgcn_s_barrier()
-#endif
+// (C3_MFMA / C3_BARRIER / C3_SEG / dd_dbg::C3_*: hooks of tools/conv3s_bound.sh's diagnostic builds, dd_debug.h)
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int NSW, int GRP = 1, bool BAND = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N)
 void dd_conv3s_kernel(const GemmParams p) {
@@ -2068,10 +1995,7 @@ void dd_conv3s_kernel(const GemmParams p) {
   static_assert(TN % 2 == 0, "TN");
   static_assert(NSW >= 3 && NSW <= 10 && (NSW - 2) * WI + XA <= 63 && 9 - (NSW - 1) >= 4, "ring depth / vmcnt");
 
-#ifdef DD_DBG_STAMP
-  uint64_t dbg_t[6];
-  const uint64_t dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  DD_STAMP_DECL();
   DD_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* abuf = reinterpret_cast<T*>(smem);                 // [2][AROWS][64]
@@ -2241,16 +2165,7 @@ void dd_conv3s_kernel(const GemmParams p) {
     }
   }
   int wslot = 0;                                        // ring slot of step s (scalar)
-#ifdef DD_DBG_STAMP
-  // per-wave segment clocks of the steady-state steps (s >= 9): [0] vmcnt wait, [1] barrier, [2] late block (MFMAs of
-  // step s-1 + DMA), [3] fragment reads issued AND returned (the stamp itself waits lgkmcnt(0)), [4] early block (DMA +
-  // MFMAs issued); waves 0 (early) and 4 (late) write theirs behind the phase stamps (tools/conv3s_stamps.py)
-  uint64_t seg[5] = {0, 0, 0, 0, 0};
-  uint64_t seg_prev = 0;
-#define C3_SEG(k) do { const uint64_t now_ = __builtin_readcyclecounter(); if (s >= 9) seg[k] += now_ - seg_prev; seg_prev = now_; } while (0)
-#else
-#define C3_SEG(k) do {} while (0)
-#endif
+  C3_SEG_DECL();
   // One (chunk, tap) step of a wave is 24 MFMAs (~410 cycles of matrix pipe), 16 fragment reads and 1.9 LDS-DMA
   // issues (an LDS-DMA blocks the issuing wave for 100-130 cycles).  Rounds 2-4 ran them as three blocks in series per
   // wave and relied on the partner wave of the SIMD to fill the holes: 1235 cycles per step for 768 of MFMA, both waves
@@ -2293,23 +2208,20 @@ void dd_conv3s_kernel(const GemmParams p) {
     if (dslot_ >= NSW) dslot_ -= NSW;
     const int dslot = dslot_;
     auto step_dma = [&]() __attribute__((always_inline)) {
-#ifndef DD_DBG_C3_NODMA
-      if constexpr (GRP == 1) {
+      if constexpr (GRP == 1 && !dd_dbg::C3_NODMA) {
         if (t < 4 && more_c) issue_a(c + 1, t * XPT, (t + 1) * XPT);
         if (s + NSW - 1 < nsteps) {
           constexpr int ta = (t + NSW - 1) % 9, ca = (t + NSW - 1) / 9;
           issue_w(c + ca, ta, dslot);
         }
       }
-#endif
     };
     if constexpr (GRP == 1) {
     // W(s) (and with it, in issue order, everything older) must have landed.  Younger loads that may stay in flight:
     // W(s+1..s+NSW-2) and the pixel pieces issued in the NSW-2 steps before this one (taps 0..3 of THIS chunk only:
     // the previous chunk's last taps issue none).  The last NSW-2 steps simply drain.  A(c+1) is complete at step
     // (c, 8), whose MFMA block gathers from it: its last piece went out at tap 3 <= 8 - (NSW - 1).
-#ifndef DD_DBG_C3_NOWAIT
-    if constexpr (!LATE) {
+    if constexpr (!LATE && !dd_dbg::C3_NOWAIT) {
       constexpr int ta0 = t - (NSW - 2) > 0 ? t - (NSW - 2) : 0, ta1 = t - 1 < 3 ? t - 1 : 3;      // taps [ta0, ta1]
       constexpr int j0 = ta0 * XPT < XA ? ta0 * XPT : XA, j1 = (ta1 + 1) * XPT < XA ? (ta1 + 1) * XPT : XA;
       constexpr int NA = ta1 >= ta0 && j1 > j0 ? j1 - j0 : 0;
@@ -2320,7 +2232,6 @@ void dd_conv3s_kernel(const GemmParams p) {
         wait_vmcnt<0>();
       }
     }
-#endif
     C3_SEG(0);
     C3_BARRIER();
     C3_SEG(1);
@@ -2342,9 +2253,7 @@ void dd_conv3s_kernel(const GemmParams p) {
     const T* ws = wring + wslot * BN * BK + (wave_n * TN * 16 + frow) * BK;
     if (++wslot == NSW) wslot = 0;
     auto wread = [&]() __attribute__((always_inline)) {
-#ifdef DD_DBG_C3_NOWREAD
-      if (s == 0)
-#endif
+      if (dd_dbg::C3_NOWREAD && s != 0) return;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int cofs = ((fchunk + 4 * ks) ^ fswz) << 3;
@@ -2365,9 +2274,7 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           mfma_j(j);
-#ifndef DD_DBG_C3_NOGATHER
-          gather_j(buf_c, tap_c, j);
-#endif
+          if constexpr (!dd_dbg::C3_NOGATHER) gather_j(buf_c, tap_c, j);
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -2398,9 +2305,8 @@ void dd_conv3s_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         mfma_j(j);
-#ifndef DD_DBG_C3_NOGATHER
-        if (have_next) gather_j(std::integral_constant<int, (t < 8 ? BUF : BUF ^ 1)>{}, std::integral_constant<int, (t + 1) % 9>{}, j);
-#endif
+        if constexpr (!dd_dbg::C3_NOGATHER)
+          if (have_next) gather_j(std::integral_constant<int, (t < 8 ? BUF : BUF ^ 1)>{}, std::integral_constant<int, (t + 1) % 9>{}, j);
         __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_s_setprio(0);
@@ -2421,9 +2327,7 @@ void dd_conv3s_kernel(const GemmParams p) {
   auto main_loop = [&](auto late_c) __attribute__((always_inline)) {
     for (int c = 0; c < nc; c += 2) {
       chunk(c, std::integral_constant<int, 0>{}, late_c);
-#ifdef DD_DBG_STAMP
-      if (c == 0) DD_STAMP(3);                                       // after the first 9 steps
-#endif
+      DD_STAMP_IF(c == 0, 3);                                        // after the first 9 steps
       if (c + 1 < nc) chunk(c + 1, std::integral_constant<int, 1>{}, late_c);
     }
   };
@@ -2444,22 +2348,8 @@ void dd_conv3s_kernel(const GemmParams p) {
   }
   // rows past the tile's instances are padding
   store_tile<T, TM, TN, false>(p, acc, row0, block_n0, wave_m, wave_n, lane, min(p.rows, row0 + vrows));
-#ifdef DD_DBG_STAMP
-  DD_STAMP(5);
-  if (threadIdx.x == 0 && p.dbg_stamps) {
-    uint64_t* o = p.dbg_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
-    for (int i = 0; i < 6; ++i) o[i] = dbg_t[i];
-    o[6] = dbg_r0;
-    o[7] = __builtin_amdgcn_s_memrealtime();
-  }
-  if ((wave == 0 || wave == 4) && lane == 0 && p.dbg_stamps) {
-    uint64_t* o = p.dbg_stamps + 65536 + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 8;
-    for (int i = 0; i < 5; ++i) o[i] = seg[i];
-    o[5] = nsteps > 9 ? nsteps - 9 : 0;
-    o[6] = wave;
-    o[7] = 1;
-  }
-#endif
+  DD_STAMP_FLUSH(p);
+  C3_SEG_FLUSH(p, wave, lane, nsteps);
 }
 
 template <typename T>
@@ -3045,10 +2935,7 @@ extern "C" int dd_gemm(const dd_gemm_desc* d, dd_stream_t stream) {
   p.ln_out_bytes = d->ln_out ? (uint32_t)((((int64_t)d->rows - 1) * d->ld_ln_out + d->n) * 2) : 0u;
   p.partial = nullptr;
   p.dbg_stamps = nullptr;
-#ifdef DD_DBG_STAMP
-  if (d->ws && d->ws_bytes >= (4 << 20))
-    p.dbg_stamps = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(d->ws) + d->ws_bytes - (1 << 20));
-#endif
+  DD_STAMP_HOST(p, d);
   if (pl.split > 1) {
     const int64_t need = DD_COUNTER_BYTES + (int64_t)pl.split * d->rows * d->n * (int64_t)sizeof(float);
     if (!d->ws || d->ws_bytes < need) return DD_ERR_WORKSPACE;
