@@ -136,3 +136,37 @@ def test_persistent_layernorm_tile_equals_its_twin(gpu, dtype, rows, k, two_sour
     assert torch.equal(outs[0][0], outs[1][0]) and _same_but_for_rare_ulps(outs[0][1], outs[1][1], dtype)
     ln = torch.nn.functional.layer_norm(outs[0][0].float(), (n,), gamma.float(), beta.float(), 1e-5)
     assert (outs[0][1].float() - ln).abs().max().item() < (4e-3 if dtype == torch.float16 else 3e-2)
+
+
+def test_persistent_tiles_random_shapes_and_operands(gpu):
+    """Sixteen seeded random problems (rows, columns with ragged tails, K in the short-loop range, either dtype, bias /
+    residual / alpha drawn at random) on every persistent tile against its dd_gemm2 twin, bit for bit, each launched twice
+    with a large unrelated launch in between (different register / LDS leftovers): the counted waits and the untracked
+    operand loads of dd_gemm4_kernel must not depend on what ran before."""
+    rng = torch.Generator().manual_seed(606)
+    pick = lambda seq: seq[int(torch.randint(len(seq), (1,), generator=rng))]
+    junk_a = torch.randn(8192, 2048, device=DEV, dtype=torch.float16)
+    for case in range(16):
+        dtype = pick([torch.float16, torch.bfloat16])
+        tile, twin = pick([(72, 52), (73, 52), (75, 44), (78, 28)])
+        rows = int(torch.randint(30000, 90000, (1,), generator=rng))
+        n = 8 * int(torch.randint(8, 170, (1,), generator=rng))
+        k = pick([320, 640, 960])
+        x, w, g = _mk(rows, n, k, dtype, 1000 + case)
+        kw = {}
+        bias = torch.randn(n, device=DEV, generator=g).to(dtype) if pick([0, 1]) else None
+        if pick([0, 1]):
+            kw["res"] = torch.randn(rows, n, device=DEV, generator=g).to(dtype)
+        if pick([0, 1]):
+            kw["alpha"] = 0.5
+        want = O.gemm(x, w, bias, tile=twin, split_k=1, **kw)
+        for rep in range(2):
+            got = O.gemm(x, w, bias, tile=tile, split_k=1, **kw)
+            assert torch.equal(got, want), (case, rep, tile, rows, n, k, dtype, sorted(kw), bias is not None)
+            (junk_a @ junk_a[:2048]).sum().item()
+        ref = x.float() @ w.float().t()
+        if bias is not None:
+            ref = ref + bias.float()
+        ref = ref * kw.get("alpha", 1.0) + (kw["res"].float() if "res" in kw else 0.0)
+        err = (got.float() - ref).abs().max().item() / (ref.abs().max().item() + 1.0)
+        assert err < 2.0 ** (-10 if dtype == torch.float16 else -7), (case, err)
