@@ -225,6 +225,7 @@ void dd_xattn320_kernel(const XAttnParams p) {
   const int nkb = (lk + 15) >> 4;                            // 16-key blocks (<= 8)
   const T* resb = p.res ? reinterpret_cast<const T*>(p.res) + grow0 * p.ldres : nullptr;
   V4 rv[2][5], bv[2];                                          // residual and bias: loaded under the last round
+  V4 lng[2], lnb4[2];                                          // LayerNorm gamma / beta of this lane's channels (ln_out), likewise
 #pragma unroll 1
   for (int round = 0; round < XH / 2; ++round) {
     xwait_vmcnt<0>();                  // this round's K / V landed (nothing younger is in flight)
@@ -245,6 +246,13 @@ void dd_xattn320_kernel(const XAttnParams p) {
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
         bv[tn] = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.bo) + wave * 32 + tn * 16 + g * 4);
+      if (p.ln_out) {                  // (round 6) not behind the epilogue's last barrier, where the round trip was exposed
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          lng[tn] = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.ln_g) + wave * 32 + tn * 16 + g * 4);
+          lnb4[tn] = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.ln_b) + wave * 32 + tn * 16 + g * 4);
+        }
+      }
       issue_w(rs_wo, 0, 2);            // slots 2, 3 = buffer 1: consumed by round 2
       issue_w(rs_wo, 1, 3);
     }
@@ -388,8 +396,15 @@ void dd_xattn320_kernel(const XAttnParams p) {
   }
   if (!p.ln_out) return;
   // ---- LayerNorm(out) over the 320 channels of every row: two-pass statistics over the ROUNDED values ---------
-  // per (row, wave) partial = sum over the wave's 32 channels; the ring region is free (gemm320 ended on a barrier)
-  float part[5];
+  // per (row, wave) partial = sum over the wave's 32 channels; the ring region is free (gemm320 ended on a barrier).
+  // Round 6: the barriers wait for the LDS partials only (a __syncthreads() also drains the stores of `out` issued just
+  // above: ~1.5 us each time), the squares go to a second array (one barrier fewer), gamma / beta are already in registers.
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  float* red2 = red + XR * XW;
 #pragma unroll
   for (int tm = 0; tm < 5; ++tm) {
     float a = 0.f;
@@ -399,10 +414,9 @@ void dd_xattn320_kernel(const XAttnParams p) {
       for (int r = 0; r < 4; ++r) a += (float)yv[tn][tm][r];
     a += __shfl_xor(a, 16, 64);
     a += __shfl_xor(a, 32, 64);
-    part[tm] = a;
     if (g == 0) red[(tm * 16 + c) * XW + wave] = a;
   }
-  __syncthreads();
+  lds_barrier();
   float mean[5];
 #pragma unroll
   for (int tm = 0; tm < 5; ++tm) {
@@ -411,7 +425,6 @@ void dd_xattn320_kernel(const XAttnParams p) {
     for (int w = 0; w < XW; ++w) a += red[(tm * 16 + c) * XW + w];
     mean[tm] = a * (1.0f / XC);
   }
-  __syncthreads();
 #pragma unroll
   for (int tm = 0; tm < 5; ++tm) {
     float a = 0.f;
@@ -421,27 +434,25 @@ void dd_xattn320_kernel(const XAttnParams p) {
       for (int r = 0; r < 4; ++r) { const float d = (float)yv[tn][tm][r] - mean[tm]; a += d * d; }
     a += __shfl_xor(a, 16, 64);
     a += __shfl_xor(a, 32, 64);
-    if (g == 0) red[(tm * 16 + c) * XW + wave] = a;
+    if (g == 0) red2[(tm * 16 + c) * XW + wave] = a;
   }
-  __syncthreads();
+  lds_barrier();
   T* lnb = reinterpret_cast<T*>(p.ln_out) + grow0 * p.ld_ln;
 #pragma unroll
   for (int tm = 0; tm < 5; ++tm) {
     float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < XW; ++w) a += red[(tm * 16 + c) * XW + w];
+    for (int w = 0; w < XW; ++w) a += red2[(tm * 16 + c) * XW + w];
     const float rstd = 1.0f / sqrtf(a * (1.0f / XC) + p.ln_eps);
     const int row = tm * 16 + c;
     if (row >= nrows) continue;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int ch = wave * 32 + tn * 16 + g * 4;
-      const V4 gv = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.ln_g) + ch);
-      const V4 bv = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(p.ln_b) + ch);
       V4 o4;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        o4[r] = (T)(((float)yv[tn][tm][r] - mean[tm]) * rstd * (float)gv[r] + (float)bv[r]);
+        o4[r] = (T)(((float)yv[tn][tm][r] - mean[tm]) * rstd * (float)lng[tn][r] + (float)lnb4[tn][r]);
       *reinterpret_cast<V4*>(lnb + (int64_t)row * p.ld_ln + ch) = o4;
     }
   }
