@@ -1,4 +1,4 @@
-"""A/B of the XCD-share column slicing (DD_XS_COLS = 1 row-major / 2 / 4 / 8 / 0 = the host's rule): hot and COLD (weights
+"""(Needs docs/experiments/r06_xs_cols.patch.txt applied: the product has no DD_XS_COLS.)  A/B of the XCD-share column slicing (DD_XS_COLS = 1 row-major / 2 / 4 / 8 / 0 = the host's rule): hot and COLD (weights
 rotated over 600 MB, as in the step) HIP-graph-chain time per launch of the dense shapes whose weight matrix does not fit an L2."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
