@@ -152,8 +152,9 @@ def dropin_loop(unet, cns, inputs, ts, coefs, steps, g_scale=2.0, start=0, laten
 
 def dropin_leg(args, dtype_name, device, fused_ms_per_step):
     """`dropin`: steps/s of dropin_loop() — the path an unchanged `val_set_gen.py` / runner validation loop gets.  Each
-    forward() replays its own HIP graph (model_base.ForwardGraphs); the three graphs of a step run back to back on the
-    caller's stream, so the ControlNet || UNet-encoder overlap of the fused sampler is not available here."""
+    forward() replays its own HIP graph (model_base.ForwardGraphs).  The UNet's graph needs the ControlNets' residuals, so
+    the ControlNet || UNet-encoder overlap of the fused sampler is not available here; the two ControlNet branches do run
+    concurrently (round 6, model_base.sibling_overlap: the second call's arguments are provably ready before the first)."""
     from dualdiff_amd.pipeline.pipeline_bev_controlnet import ddim_schedule
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
     unet, cns = build_models(dtype, device)

@@ -25,6 +25,112 @@ VARLEN_CONTEXT = os.environ.get("DD_VARLEN_CONTEXT", "1") != "0"
 # model (ControlNet residuals / tokens -> UNet, as pipeline_bev_controlnet.py:476-484 does with one branch) is read in
 # place instead of through a copy.  Weak: the entries die with the graph that owns the buffers.
 _STATIC_OUT = weakref.WeakValueDictionary()
+# Sibling overlap (round 6): two models whose forward() calls follow each other on one stream with inputs that were all
+# ready before the FIRST call run concurrently (see sibling_overlap below).  DD_SIBLING_OVERLAP=0 switches it off.
+SIBLING_OVERLAP = os.environ.get("DD_SIBLING_OVERLAP", "1") != "0"
+_SIB = __import__("threading").local()           # .window: the latest forward() entry on this thread
+_SIB_HOLD_BYTES = (64 << 20, 192 << 20)          # per tensor / per entry: larger inputs are not held (and never proven ready)
+
+
+def _flat_tensors(obj, out):
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _flat_tensors(v, out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _flat_tensors(v, out)
+    return out
+
+
+def _ident(t):
+    """(where the bytes are, how they are viewed), version — or None when that cannot be known (inference tensors do not
+    count versions; non-CUDA tensors)."""
+    try:
+        if not t.is_cuda:
+            return None
+        return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype), t._version
+    except RuntimeError:
+        return None
+
+
+class _Seen:
+    """The tensor arguments of one forward() entry: key -> (the tensor, held so that its memory cannot be re-used for
+    something else while this record lives; its version at that moment), the event recorded on the caller's stream at
+    that moment and that stream's handle."""
+
+    def __init__(self, tensors, owner, stream):
+        self.items = {}
+        held = 0
+        for t in tensors:
+            idv, nbytes = _ident(t), t.numel() * t.element_size()
+            if idv is None or nbytes > _SIB_HOLD_BYTES[0] or held + nbytes > _SIB_HOLD_BYTES[1]:
+                continue                         # cannot be vouched for later (the ControlNet residuals of a UNet call, say)
+            held += nbytes
+            self.items[idv[0]] = (t, idv[1])
+        self.owner = weakref.ref(owner)
+        self.stream = (stream.device_index, stream.cuda_stream)
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def vouches(self, t):
+        idv = _ident(t)
+        if idv is None:
+            return False
+        held = self.items.get(idv[0])
+        return held is not None and held[1] == idv[1] and held[0]._version == idv[1]
+
+
+def sibling_overlap(fwd):
+    """Decorator of the two public forward()s.  The reference's sampler calls its ControlNet branches one after the other
+    and only then the UNet (pipeline_bev_controlnet.py:405-431, 476-484); the branches do not depend on each other, but a
+    drop-in forward() has no way to say so — every call is enqueued behind the previous one on the caller's stream (the
+    fused sampler of this package overlaps them on three streams; the drop-in loop ran at its one-stream rate, 0.83).
+    Here each forward() entry records (event on the caller's stream, its tensor arguments with their versions).  A call
+    of ANOTHER model whose every tensor argument is vouched for — the same bytes, view and version as an argument of the
+    previous entry on this stream, or of this model's own previous call on it — needs nothing that was enqueued after
+    that entry: it runs on the model's side stream behind that entry's event, i.e. concurrently with the previous model,
+    and the caller's stream waits for it before forward() returns (outputs are recorded on the caller's stream for the
+    allocator).  Anything else — a new tensor (say, one computed from the sibling's outputs), an in-place update since
+    (version), tensors too large to hold, inference tensors, alias outputs, eager or sharded models, a capture in
+    progress — takes the ordinary path.  Results are bit-identical either way (tests/test_forward_graphs_gpu.py)."""
+    import functools
+
+    @functools.wraps(fwd)
+    def wrapper(self, *args, **kwargs):
+        if not (SIBLING_OVERLAP and GRAPH_FORWARD and self.graph_forward is True) or not torch.cuda.is_available() \
+                or torch.cuda.is_current_stream_capturing() or self._graphs() is None:
+            _SIB.window = None
+            return fwd(self, *args, **kwargs)
+        tensors = _flat_tensors((args, kwargs), [])
+        cur = torch.cuda.current_stream()
+        entry = _Seen(tensors, self, cur)
+        here = (cur.device_index, cur.cuda_stream)
+        window, mine = getattr(_SIB, "window", None), self.__dict__.get("_sib_prev")
+        _SIB.window = entry
+        self.__dict__["_sib_prev"] = entry
+        ok = window is not None and window.stream == here and window.owner() is not self \
+            and window.owner() is not None and len(tensors) > 0
+        if ok:
+            mine_ok = mine is not None and mine.stream == here
+            ok = all(window.vouches(t) or (mine_ok and mine.vouches(t)) for t in tensors)
+        if not ok:
+            return fwd(self, *args, **kwargs)
+        side = self.__dict__.get("_sib_stream")
+        if side is None:
+            side = self.__dict__["_sib_stream"] = torch.cuda.Stream()
+        side.wait_event(window.event)
+        with torch.cuda.stream(side):
+            out = fwd(self, *args, **kwargs)
+        cur.wait_stream(side)
+        res = out.to_tuple() if hasattr(out, "to_tuple") else (out.sample if hasattr(out, "sample") else out)
+        for t in _flat_tensors(res, []):
+            t.record_stream(cur)
+        self.__dict__["_sib_overlapped"] = self.__dict__.get("_sib_overlapped", 0) + 1
+        return out
+
+    return wrapper
 
 
 class ForwardGraphs:
@@ -53,9 +159,9 @@ class ForwardGraphs:
     rewritten through `.data` must be followed by `model._invalidate()`, as for the packed-weight caches.
     A capture that fails (a non-capturable op in a user-modified block, no memory for the private pool) marks its key
     eager-only: the call and every later one with that key run eagerly, with one warning.
-    Replays of graphs captured on recycled side streams share ops.workspace buffers: they are safe because all replays of
-    one process are launched from the caller's CURRENT stream, one after the other — do not replay forward graphs of one
-    model concurrently from several streams."""
+    Scratch buffers (ops.workspace) are per ForwardGraphs (ops.workspace_owner), not per capture stream: the graphs of two
+    MODELS may replay concurrently (sibling_overlap); those of one model share its buffers and are always replayed one
+    after the other — do not replay forward graphs of one model concurrently from several streams."""
 
     # A key is recorded the SECOND time it is seen (the first call runs eagerly): a caller that uses a shape once
     # should not pay an eager run AND a capture for it.  At most MAX_ENTRIES graphs per model stay alive (least
@@ -150,8 +256,11 @@ class ForwardGraphs:
         s = torch.cuda.Stream()
         s.wait_stream(cur)
         g = torch.cuda.CUDAGraph()
+        from .. import ops as _ops
         try:
-            with torch.cuda.stream(s):
+            # scratch buffers of this model's graphs are its own (ops.workspace_owner): graphs of two models may replay
+            # concurrently (sibling_overlap), and pooled stream handles are no identity
+            with torch.cuda.stream(s), _ops.workspace_owner(id(self)):
                 impl(static)                          # eager on the capture stream: tuning, packing, workspaces of this stream
                 torch.cuda.synchronize()
                 with torch.cuda.graph(g, stream=s):

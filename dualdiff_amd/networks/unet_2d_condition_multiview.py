@@ -21,7 +21,7 @@ from .blocks import BasicMultiviewTransformerBlock
 from .layers import (BasicTransformerBlock, prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, GroupNorm,
                      TimestepEmbedding, Timesteps, UNetMidBlock2DCrossAttn, UpBlock2D, as_nchw_view,
                      run_down_block, run_up_block, to_nhwc, CTX_BASE, context_keys, ctx_capacity, lk_const)
-from .model_base import ModelBase
+from .model_base import ModelBase, sibling_overlap
 
 
 def _at_capacity(ctx, cap):
@@ -216,6 +216,7 @@ class UNet2DConditionModelMultiview(ModelBase):
         t = t.to(device=device, dtype=torch.float32).reshape(-1)
         return t.expand(m).contiguous()
 
+    @sibling_overlap
     def forward(
         self,
         sample: torch.Tensor,

@@ -28,7 +28,7 @@ from .box_adapter import Adapter_XFormersAttnProcessor, XFormersAttnProcessor  #
 from .embedder import get_embedder
 from .layers import (prefetch_cross_kv, drop_prefetched_kv, CrossKVBank, Conv3x3, CrossAttnDownBlock2D, DownBlock2D, Linear, TimestepEmbedding, Timesteps,
                      UNetMidBlock2DCrossAttn, as_nchw_view, box_capacity, context_keys, lk_const, run_down_block, to_nhwc)
-from .model_base import ModelBase
+from .model_base import ModelBase, sibling_overlap
 from .output_cls import BEVControlNetOutput
 from .txt_con_fusion import txt_con_XFormersAttn, txt_con_XFormersAttn_plus
 
@@ -400,6 +400,7 @@ class BEVControlNetModel(ModelBase):
         outs.append((self.controlnet_mid_block.run(x, alpha=scales[-1], out=dst, accumulate=accumulate), h, w))
         return outs
 
+    @sibling_overlap
     def forward(
         self,
         sample: torch.Tensor,

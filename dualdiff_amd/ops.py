@@ -5,6 +5,7 @@ current stream.  Tensors are token-major / NHWC 2-D views (rows, channels) in fp
 There is no eager fallback: a non-GPU tensor raises.
 """
 import ctypes
+import threading as _threading
 
 import torch
 
@@ -327,14 +328,35 @@ _WS_RETIRED = []          # such buffers after they were outgrown: kept alive fo
 _DBG_STAMP_WS = _os.environ.get("DD_DBG_STAMP_WS", "0") == "1"
 
 
+_WS_OWNER = _threading.local()
+
+
+class workspace_owner:
+    """`with workspace_owner(token):` scratch buffers handed out inside are keyed by `token` instead of the current
+    stream's handle.  model_base.ForwardGraphs records each model's graphs under its own token: torch's stream handles
+    are pooled and re-used, so two models' capture streams can share a handle — harmless while forward graphs replay one
+    after the other, a race once two models' graphs replay concurrently (round 6: sibling overlap)."""
+
+    def __init__(self, token):
+        self.token = token
+
+    def __enter__(self):
+        self.prev = getattr(_WS_OWNER, "token", None)
+        _WS_OWNER.token = self.token
+
+    def __exit__(self, *exc):
+        _WS_OWNER.token = self.prev
+
+
 def workspace(nbytes, device, kind="gemm"):
-    """Grow-only fp32 scratch buffer per (device, stream, kind): kernels on concurrent streams must
-    not share scratch, and the split-K buffer (whose leading counter region dd_gemm keeps at zero)
+    """Grow-only fp32 scratch buffer per (device, stream — or workspace_owner token —, kind): kernels on concurrent
+    streams must not share scratch, and the split-K buffer (whose leading counter region dd_gemm keeps at zero)
     is never lent to GroupNorm.  Zero-filled on allocation; allocate before graph capture.
     A buffer that was handed out during a capture is never freed (torch's stream handles are pooled and
     re-used, so a later, larger eager workload can outgrow a buffer that a live graph still writes to)."""
+    owner = getattr(_WS_OWNER, "token", None)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream, kind)
+           torch.cuda.current_stream().cuda_stream if owner is None else ("owner", owner), kind)
     ws = _WS.get(key)
     need = max(int(nbytes), _WS_MIN_BYTES)
     capturing = torch.cuda.is_current_stream_capturing()
