@@ -103,7 +103,8 @@ def sibling_overlap(fwd):
                 or torch.cuda.is_current_stream_capturing() or self._graphs() is None:
             _SIB.window = None
             return fwd(self, *args, **kwargs)
-        tensors = _flat_tensors((args, kwargs), [])
+        # (host tensors — a CPU timestep, say — are read at call time: nothing to prove)
+        tensors = [t for t in _flat_tensors((args, kwargs), []) if t.is_cuda]
         cur = torch.cuda.current_stream()
         entry = _Seen(tensors, self, cur)
         here = (cur.device_index, cur.cuda_stream)
@@ -121,7 +122,8 @@ def sibling_overlap(fwd):
         if side is None:
             side = self.__dict__["_sib_stream"] = torch.cuda.Stream()
         side.wait_event(window.event)
-        with torch.cuda.stream(side):
+        from .. import ops as _ops
+        with torch.cuda.stream(side), _ops.workspace_owner(("sibling", id(self))):   # its eager launches: own scratch too
             out = fwd(self, *args, **kwargs)
         cur.wait_stream(side)
         res = out.to_tuple() if hasattr(out, "to_tuple") else (out.sample if hasattr(out, "sample") else out)

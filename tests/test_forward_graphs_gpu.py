@@ -332,6 +332,10 @@ def test_sibling_controlnets_run_concurrently_only_when_every_input_was_ready(gp
         assert cns[1].__dict__["_sib_overlapped"] == 2   # steps 0 and 1; steps 2 (new tensor) and 3 (in-place update) not
         for g, w in zip(got, want):
             assert _same(g, w)
+        for _ in range(4):                               # again and again: two graphs in flight must not share scratch
+            for g, w in zip(run(), want):
+                assert _same(g, w)
+        cns[1].__dict__["_sib_overlapped"] = 2
         # the UNet behind them (its residuals are new tensors): ordinary path, same numbers
         lmi = torch.cat([lat0] * 2)
         a, b = call(cns[0], 0, lmi, ts[0]), call(cns[1], 1, lmi, ts[0])
