@@ -336,6 +336,23 @@ def test_sibling_controlnets_run_concurrently_only_when_every_input_was_ready(gp
             for g, w in zip(run(), want):
                 assert _same(g, w)
         cns[1].__dict__["_sib_overlapped"] = 2
+        # the same model twice in a row, a call from another stream, inference tensors: ordinary path, same numbers
+        lmi = torch.cat([lat0] * 2)
+        ref = [x.clone() for x in call(cns[1], 1, lmi, ts[1])]
+        n0 = cns[1].__dict__["_sib_overlapped"]
+        assert _same(call(cns[1], 1, lmi, ts[1]), ref) and cns[1].__dict__["_sib_overlapped"] == n0
+        call(cns[0], 0, lmi, ts[1])
+        other = torch.cuda.Stream()
+        other.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(other):
+            on_other = [x.clone() for x in call(cns[1], 1, lmi, ts[1])]
+        torch.cuda.current_stream().wait_stream(other)
+        assert _same(on_other, ref) and cns[1].__dict__["_sib_overlapped"] == n0
+        with torch.inference_mode():
+            lmi_i = torch.cat([lat0] * 2)
+            call(cns[0], 0, lmi_i, ts[1])
+            assert _same(call(cns[1], 1, lmi_i, ts[1]), ref) and cns[1].__dict__["_sib_overlapped"] == n0
+        cns[1].__dict__["_sib_overlapped"] = 2
         # the UNet behind them (its residuals are new tensors): ordinary path, same numbers
         lmi = torch.cat([lat0] * 2)
         a, b = call(cns[0], 0, lmi, ts[0]), call(cns[1], 1, lmi, ts[0])
