@@ -28,6 +28,9 @@ _STATIC_OUT = weakref.WeakValueDictionary()
 # Sibling overlap (round 6): two models whose forward() calls follow each other on one stream with inputs that were all
 # ready before the FIRST call run concurrently (see sibling_overlap below).  DD_SIBLING_OVERLAP=0 switches it off.
 SIBLING_OVERLAP = os.environ.get("DD_SIBLING_OVERLAP", "1") != "0"
+# storages of forward-graph OUTPUT buffers: a replay rewrites them without any version count (`graph_forward = "alias"` hands
+# them to the caller), so they can never be vouched for
+_STATIC_STORAGE = set()
 _SIB = __import__("threading").local()           # .window: the latest forward() entry on this thread
 _SIB_HOLD_BYTES = (64 << 20, 192 << 20)          # per tensor / per entry: larger inputs are not held (and never proven ready)
 
@@ -49,6 +52,8 @@ def _ident(t):
     count versions; non-CUDA tensors)."""
     try:
         if not t.is_cuda:
+            return None
+        if t.untyped_storage().data_ptr() in _STATIC_STORAGE:
             return None
         return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype), t._version
     except RuntimeError:
@@ -92,7 +97,9 @@ def sibling_overlap(fwd):
     previous entry on this stream, or of this model's own previous call on it — needs nothing that was enqueued after
     that entry: it runs on the model's side stream behind that entry's event, i.e. concurrently with the previous model,
     and the caller's stream waits for it before forward() returns (outputs are recorded on the caller's stream for the
-    allocator).  Anything else — a new tensor (say, one computed from the sibling's outputs), an in-place update since
+    allocator).  The version count is the proof that nothing rewrote an argument since: memory that is rewritten WITHOUT
+    one — the output buffers of a forward graph handed out by `graph_forward = "alias"` (_STATIC_STORAGE); a foreign
+    extension writing through raw pointers, which this cannot see — must not be relied on; the former is refused.  Anything else — a new tensor (say, one computed from the sibling's outputs), an in-place update since
     (version), tensors too large to hold, inference tensors, alias outputs, eager or sharded models, a capture in
     progress — takes the ordinary path.  Results are bit-identical either way (tests/test_forward_graphs_gpu.py)."""
     import functools
@@ -272,6 +279,7 @@ class ForwardGraphs:
         for o in out:
             if torch.is_tensor(o):
                 _STATIC_OUT[o.data_ptr()] = o
+                _STATIC_STORAGE.add(o.untyped_storage().data_ptr())
         return {"graph": g, "static": static, "alias": alias, "out": out, "epoch": _layers.CACHE_EPOCH[0]}
 
 

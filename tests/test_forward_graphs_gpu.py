@@ -353,6 +353,39 @@ def test_sibling_controlnets_run_concurrently_only_when_every_input_was_ready(gp
             call(cns[0], 0, lmi_i, ts[1])
             assert _same(call(cns[1], 1, lmi_i, ts[1]), ref) and cns[1].__dict__["_sib_overlapped"] == n0
         cns[1].__dict__["_sib_overlapped"] = 2
+        # an argument that lives in another model's graph-owned OUTPUT buffer (graph_forward = "alias": rewritten by every
+        # replay without a version count) is never vouched for.  Branch 0 hands out views of its buffers; the UNet call
+        # behind it opens the window; branch 1 gets the SAME objects at every step — and, as its text tokens, a view of
+        # branch 0's tokens (camera token first: it follows the camera parameters, which change from step to step)
+        cns[0].graph_forward = "alias"
+        lmi_c, t_c = torch.cat([lat0] * 2), ts[0]
+
+        def chained():
+            outs = []
+            for k in range(6):
+                down, mid, ctx = cns[0](lmi_c, t_c.expand(2), cam * (1.0 + 0.05 * k), boxes[0], prompt, conds[0], conditioning_scale=1.0,
+                                        guess_mode=False, return_dict=False, use_aug_text=False)
+                unet(lmi_c.reshape(-1, *lmi_c.shape[2:]), t_c, encoder_hidden_states=ctx).sample
+                down, mid, ctx1 = cns[1](lmi_c, t_c.expand(2), cam, boxes[1], ctx[::6, 0:77], conds[1], conditioning_scale=1.0,
+                                         guess_mode=False, return_dict=False, use_aug_text=False)
+                outs.append([x.clone() for x in list(down) + [mid, ctx1]])
+            torch.cuda.synchronize()
+            return outs
+
+        MB.SIBLING_OVERLAP = False
+        try:
+            chained()
+            want_c = chained()
+        finally:
+            MB.SIBLING_OVERLAP = True
+        chained()
+        n0 = cns[1].__dict__["_sib_overlapped"]
+        got_c = chained()
+        assert cns[1].__dict__["_sib_overlapped"] == n0
+        for g, w in zip(got_c, want_c):
+            assert _same(g, w)
+        assert not _same(want_c[0], want_c[1])           # the camera parameters do reach branch 1 through those tokens
+        cns[0].graph_forward = True
         # the UNet behind them (its residuals are new tensors): ordinary path, same numbers
         lmi = torch.cat([lat0] * 2)
         a, b = call(cns[0], 0, lmi, ts[0]), call(cns[1], 1, lmi, ts[0])
