@@ -35,6 +35,12 @@ _SIB = __import__("threading").local()           # .window: the latest forward()
 _SIB_HOLD_BYTES = (64 << 20, 192 << 20)          # per tensor / per entry: larger inputs are not held (and never proven ready)
 
 
+def sibling_barrier():
+    """Forget the latest forward() entry of this thread: called by code of this package that rewrites tensors through raw
+    pointers outside the public forward()s (the fused sampler's step), so that nothing it touched can be vouched for."""
+    _SIB.window = None
+
+
 def _flat_tensors(obj, out):
     if torch.is_tensor(obj):
         out.append(obj)

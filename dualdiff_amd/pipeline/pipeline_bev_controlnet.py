@@ -297,6 +297,8 @@ class BEVDenoiser:
 
     def step(self, i):
         """Denoising step i (0-based) on the current latents."""
+        from ..networks.model_base import sibling_barrier
+        sibling_barrier()                                # this step rewrites its buffers in place (no version counts)
         self._set_step(i)
         if self.use_graph:
             if self._graph is None:
