@@ -105,9 +105,10 @@ def sibling_overlap(fwd):
     and the caller's stream waits for it before forward() returns (outputs are recorded on the caller's stream for the
     allocator).  The version count is the proof that nothing rewrote an argument since: memory that is rewritten WITHOUT
     one — the output buffers of a forward graph handed out by `graph_forward = "alias"` (_STATIC_STORAGE); a foreign
-    extension writing through raw pointers, which this cannot see — must not be relied on; the former is refused.  Anything else — a new tensor (say, one computed from the sibling's outputs), an in-place update since
-    (version), tensors too large to hold, inference tensors, alias outputs, eager or sharded models, a capture in
-    progress — takes the ordinary path.  Results are bit-identical either way (tests/test_forward_graphs_gpu.py)."""
+    extension writing through raw pointers, which this cannot see — must not be relied on; the former is refused.
+    Anything else — a new tensor (say, one computed from the sibling's outputs), an in-place update since (version),
+    tensors too large to hold, inference tensors, alias outputs, eager or sharded models, a capture in progress — takes
+    the ordinary path.  Results are bit-identical either way (tests/test_forward_graphs_gpu.py)."""
     import functools
 
     @functools.wraps(fwd)
